@@ -1,0 +1,135 @@
+/* include/snesimage_hip.h — C ABI of libsnesimage_hip.so, the MI355X (gfx950) implementation of
+ * snesimage's palette-optimizer hot path.
+ *
+ * The reference (aexoden/snesimage, Rust) has no FFI or plugin seam: the hot path is the private
+ * method set of `struct OptimizedImage` (/root/reference/src/lib.rs:33-626) called from `run()`
+ * (lib.rs:851, 893-910, 988, 1002, 1021).  This header defines that seam as a C ABI; each entry
+ * point names the reference method it replaces.  A Rust host binds it with an `extern "C"` block
+ * (INTEGRATION.md).  Conventions:
+ *   - every function returns 0 on success and a negative code on failure; the message is available
+ *     from snesimage_last_error() (thread-local, owned by the library) — the C analogue of the
+ *     reference's anyhow::Result + context strings (lib.rs:82, 186, 212 ...; main.rs:16-19);
+ *   - snesimage_ctx owns all device memory (the reference struct owns its Vecs, lib.rs:33-43);
+ *     the caller owns every pointer it passes; host pointers are copied during the call;
+ *   - a ctx is bound to one HIP device and one stream and is not thread-safe (the reference is
+ *     single-threaded); independent contexts may be used from different threads;
+ *   - there is no CPU fallback: creation fails if no HIP device is usable.
+ * Colours cross the boundary as raw 5-bit (r,g,b) byte triples — `SnesColor.data` (lib.rs:629-638)
+ * — or as BGR555 words where the reference itself emits them (`as_u16`, lib.rs:679-681).
+ */
+#ifndef SNESIMAGE_HIP_H
+#define SNESIMAGE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct snesimage_ctx snesimage_ctx;
+
+/* config.rs:20-30 (--dither, --perceptual-palettes, --nes) */
+enum { SNES_DITHER = 1, SNES_PERCEPTUAL = 2, SNES_NES = 4 };
+/* optimizer methods: lib.rs:191 (random), :286 (channel), :242 (nes) */
+enum { SNES_METHOD_RANDOM = 0, SNES_METHOD_CHANNEL = 1, SNES_METHOD_NES = 2 };
+
+enum {
+    SNES_OK = 0,
+    SNES_ERR_ARG = -1,       /* bad argument (sizes, null pointers, slot out of range) */
+    SNES_ERR_HIP = -2,       /* a HIP runtime call failed */
+    SNES_ERR_STATE = -3,     /* call not valid in the current state */
+    SNES_ERR_KMEANS = -4,    /* cogset precondition 2 <= k < n violated (the reference panics) */
+    SNES_ERR_UNSUPPORTED = -5
+};
+
+/* OptimizedImage::new — lib.rs:46-65.  rgba: w*h*4 bytes, row-major RGBA8.  w must be 256 (tile
+ * stride hard-coded to 32, lib.rs:58,565); h a power of two in [8,256].  sub_count*sub_size <= 253.
+ * device: HIP device ordinal (>= 0). */
+int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t sub_count,
+                         uint32_t sub_size, uint32_t flags, int32_t device, snesimage_ctx **out);
+void snesimage_destroy(snesimage_ctx *ctx);
+
+/* Plumbing: run all subsequent work on an existing hipStream_t (e.g. torch's current stream).
+ * NULL restores the context's own stream. */
+int32_t snesimage_set_stream(snesimage_ctx *ctx, void *hip_stream);
+/* Block until all work queued by this context has finished. */
+int32_t snesimage_sync(snesimage_ctx *ctx);
+/* Candidates scored per internal launch group (bounds the workspace); default 256. */
+int32_t snesimage_set_chunk(snesimage_ctx *ctx, uint32_t chunk);
+
+int32_t snesimage_initialize_tiles(snesimage_ctx *ctx);     /* lib.rs:79-189  */
+int32_t snesimage_recalculate_palettes(snesimage_ctx *ctx); /* lib.rs:407-415 */
+int32_t snesimage_optimize(snesimage_ctx *ctx);             /* lib.rs:425-501 */
+int32_t snesimage_error(snesimage_ctx *ctx, double *out);   /* lib.rs:503-548 */
+
+/* The loop body of lib.rs:205-220 / 252-262 / 296-306 for an explicit candidate list: for each
+ * k < n, entry (palette,index) := rgb5[3k..3k+2], optimize(), error() -> errors[k].  The context's
+ * palette and palette_map are left unchanged.  Host pointers; synchronous. */
+int32_t snesimage_score_candidates(snesimage_ctx *ctx, uint32_t palette, uint32_t index,
+                                   const uint8_t *rgb5, uint32_t n, double *errors);
+/* Same with device pointers, asynchronous on the context's stream (no host synchronisation).
+ * maps_out (optional, device, n*w*h bytes) receives each candidate's palette_map. */
+int32_t snesimage_score_candidates_device(snesimage_ctx *ctx, uint32_t palette, uint32_t index,
+                                          const uint8_t *d_rgb5, uint32_t n, double *d_errors,
+                                          uint8_t *d_maps_out);
+
+/* One optimizer call — optimize_palette_entry_{random,channel,nes} (lib.rs:191-328) followed by
+ * lib.rs:906-910.  Random candidates come from the counter RNG keyed (seed, step_id);
+ * n_random = 0 means the reference's 64 (lib.rs:205).  best_error / best_rgb5 may be NULL. */
+int32_t snesimage_step(snesimage_ctx *ctx, uint32_t method, uint32_t palette, uint32_t index,
+                       uint32_t channel, uint64_t seed, uint64_t step_id, uint32_t n_random,
+                       double *best_error, uint8_t *best_rgb5);
+/* The same without any host synchronisation; results via snesimage_last_step(). */
+int32_t snesimage_step_async(snesimage_ctx *ctx, uint32_t method, uint32_t palette, uint32_t index,
+                             uint32_t channel, uint64_t seed, uint64_t step_id, uint32_t n_random);
+int32_t snesimage_last_step(snesimage_ctx *ctx, double *best_error, uint8_t *best_rgb5,
+                            int32_t *best_k);
+
+/* Split-phase step for candidate sharding across GPUs.  Phase 1 scores the
+ * candidates k with k % shard_count == shard_rank of the n_total candidates of this call and
+ * writes d_errors[k] (device, n_total doubles; +inf for candidates owned by other ranks).  The
+ * caller min-all-reduces d_errors across ranks (RCCL), then phase 2 applies the reference's
+ * acceptance rule (strict <, ascending k, lib.rs:216-219) identically on every rank. */
+int32_t snesimage_step_begin(snesimage_ctx *ctx, uint32_t method, uint32_t palette, uint32_t index,
+                             uint32_t channel, uint64_t seed, uint64_t step_id, uint32_t n_total,
+                             uint32_t shard_rank, uint32_t shard_count, double *d_errors);
+int32_t snesimage_step_commit(snesimage_ctx *ctx, const double *d_errors);
+
+/* State access (the reference mutates these fields directly: lib.rs:1015 and the GUI). */
+int32_t snesimage_get_tile_palettes(snesimage_ctx *ctx, uint8_t *out /*1024*/);
+int32_t snesimage_set_tile_palettes(snesimage_ctx *ctx, const uint8_t *in /*1024*/);
+int32_t snesimage_get_palette_rgb5(snesimage_ctx *ctx, uint8_t *out /*count*size*3*/);
+int32_t snesimage_set_palette_rgb5(snesimage_ctx *ctx, const uint8_t *in);
+int32_t snesimage_get_palette_u16(snesimage_ctx *ctx, uint16_t *out /*count*size; lib.rs:679-681*/);
+int32_t snesimage_get_palette_map(snesimage_ctx *ctx, uint8_t *out /*w*h*/);
+int32_t snesimage_set_palette_map(snesimage_ctx *ctx, const uint8_t *in);
+int32_t snesimage_as_rgba(snesimage_ctx *ctx, uint8_t *out /*w*h*4; lib.rs:550-577*/);
+/* as_json().to_string() — lib.rs:579-625, 1002.  Returns the byte count needed including the
+ * terminating NUL (negative on error) and writes at most cap bytes. */
+int64_t snesimage_as_json(snesimage_ctx *ctx, char *out, int64_t cap);
+
+/* Candidate generator used by SNES_METHOD_RANDOM (host helper; replaces the reference's unseeded
+ * rand::rng() of lib.rs:201-208). */
+void snesimage_random_candidates(uint64_t seed, uint64_t step_id, uint32_t n, uint8_t *rgb5);
+/* Slot scheduler of lib.rs:881-933 (host helper): reports the method for the current slot and
+ * advances (palette, index, channel, step). */
+void snesimage_schedule_next(uint32_t sub_count, uint32_t sub_size, int32_t nes, uint32_t *palette,
+                             uint32_t *index, uint32_t *channel, uint32_t *step, uint32_t *method);
+
+/* Device-side evaluation of the deterministic math used by the kernels, for bit-parity tests:
+ * op 0 sin, 1 cos, 2 exp(x<=0), 3 cbrt, 4 atan2(y,x), 5 CIEDE2000(lab x[3i..], lab y[3i..]),
+ * 6 sRGB8->Lab (x holds r,g,b as floats, out 3 per item). Host pointers. */
+int32_t snesimage_debug_math(int32_t device, int32_t op, const float *x, const float *y, uint32_t n,
+                             float *out);
+/* Average duration in milliseconds of the scoring kernels recorded by the library's own HIP
+ * events since the last reset (bench.py's roofline leg). which: 0 = all scoring kernels of a
+ * call.  Returns negative if timing was not enabled. */
+int32_t snesimage_timing_enable(snesimage_ctx *ctx, int32_t on);
+int32_t snesimage_timing_read(snesimage_ctx *ctx, double *total_ms, uint64_t *launches,
+                              uint64_t *candidates);
+
+const char *snesimage_last_error(void);
+const char *snesimage_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

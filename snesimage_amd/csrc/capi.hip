@@ -1,0 +1,780 @@
+// snesimage_amd/csrc/capi.hip — libsnesimage_hip.so: context, launch sequencing and the C ABI of
+// include/snesimage_hip.h.  gfx950 only; there is no CPU path in this library.
+#include "../../include/snesimage_hip.h"
+#include "kernels.hpp"
+#include "kernels_opt.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace snes;
+
+namespace {
+
+thread_local std::string g_err;
+int32_t fail(int32_t code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                                              \
+    do {                                                                                                          \
+        hipError_t e_ = (expr);                                                                                   \
+        if (e_ != hipSuccess) return fail(SNES_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+#define CHECK(expr)                                                                                               \
+    do {                                                                                                          \
+        int32_t rc_ = (expr);                                                                                     \
+        if (rc_ != SNES_OK) return rc_;                                                                           \
+    } while (0)
+
+// ssimulacra2 build.rs: recursive-Gaussian constants for sigma = 1.5 (binary64, then f32)
+BlurK make_blur_constants() {
+    const double SIGMA = 1.5, PI = 3.14159265358979323846;
+    const double radius = std::round(std::fma(3.2795, SIGMA, 0.2546));
+    const double w0 = PI / (2.0 * radius);
+    const double omega[3] = {w0, 3.0 * w0, 5.0 * w0};
+    const double p1 = 1.0 / std::tan(0.5 * omega[0]), p3 = -1.0 / std::tan(0.5 * omega[1]), p5 = 1.0 / std::tan(0.5 * omega[2]);
+    const double r1 = p1 * p1 / std::sin(omega[0]), r3 = -p3 * p3 / std::sin(omega[1]), r5 = p5 * p5 / std::sin(omega[2]);
+    const double nhs2 = -0.5 * SIGMA * SIGMA, rr = 1.0 / radius;
+    double rho[3];
+    for (int i = 0; i < 3; i++) rho[i] = std::exp(nhs2 * omega[i] * omega[i]) * rr;
+    const double d13 = std::fma(p1, r3, -r1 * p3), d35 = std::fma(p3, r5, -r3 * p5), d51 = std::fma(p5, r1, -r5 * p1);
+    const double rd13 = 1.0 / d13, z15 = d35 * rd13, z35 = d51 * rd13;
+    const double A[3][3] = {{p1, p3, p5}, {r1, r3, r5}, {z15, z35, 1.0}};
+    const double gam[3] = {1.0, std::fma(radius, radius, -SIGMA * SIGMA), std::fma(z15, rho[0], z35 * rho[1]) + rho[2]};
+    const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                       A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+    double inv[3][3];
+    inv[0][0] = (A[1][1] * A[2][2] - A[1][2] * A[2][1]) / det; inv[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) / det;
+    inv[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) / det; inv[1][0] = (A[1][2] * A[2][0] - A[1][0] * A[2][2]) / det;
+    inv[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) / det; inv[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) / det;
+    inv[2][0] = (A[1][0] * A[2][1] - A[1][1] * A[2][0]) / det; inv[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / det;
+    inv[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / det;
+    BlurK K;
+    for (int i = 0; i < 3; i++) {
+        const double beta = inv[i][0] * gam[0] + inv[i][1] * gam[1] + inv[i][2] * gam[2];
+        K.n2[i] = (float)(-beta * std::cos(omega[i] * (radius + 1.0)));
+        K.d1[i] = (float)(-2.0 * std::cos(omega[i]));
+    }
+    return K;
+}
+
+// yuvxyb sRGB EOTF on v/255 (lib.rs:511-513) and palette's Srgb::into_linear on v/255 (lib.rs:1092-1097).
+// powf is evaluated through binary64 pow and rounded once.
+void make_eotf_tables(float *ssim_eotf, float *lab_eotf) {
+    for (int v = 0; v < 256; v++) {
+        const float x = (float)v / 255.0f;
+        ssim_eotf[v] = x < 0.04045f ? x / 12.92f : (float)std::pow((double)((x + 0.055f) / 1.055f), (double)2.4f);
+        lab_eotf[v] = x <= 0.04045f ? (float)(1.0 / 12.92) * x
+                                    : (float)std::pow((double)std::fmaf(x, (float)(1.0 / 1.055), (float)(0.055 / 1.055)), (double)2.4f);
+    }
+}
+
+inline uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+template <typename T> void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+} // namespace
+
+struct snesimage_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    uint32_t W = 0, H = 0, sub_count = 0, sub_size = 0, flags = 0;
+    int ncol = 0;
+    bool dither = false, perceptual = false, nes = false;
+    Geom G{};
+    BlurK K{};
+    size_t npx = 0, src_floats = 0;
+    uint32_t chunk = 256, chunk_alloc = 0;
+
+    std::vector<uint8_t> h_orig; float h_eotf[256], h_lab_eotf[256];
+
+    // device state
+    uint8_t *d_orig = nullptr, *d_tile_pal = nullptr, *d_colors = nullptr, *d_map = nullptr;
+    unsigned long long *d_pack = nullptr, *d_packT = nullptr;
+    float *d_eotf = nullptr, *d_lab_eotf = nullptr;
+    uint32_t *d_pal_rgb8 = nullptr; float *d_pal_lin = nullptr, *d_pal_xyb = nullptr, *d_pal_lab = nullptr;
+    float *d_lin0 = nullptr, *d_img1 = nullptr, *d_img1T = nullptr, *d_mu1 = nullptr, *d_s11 = nullptr;
+    float *d_labpx = nullptr, *d_labpxT = nullptr;
+    // per-chunk workspace
+    float *d_work = nullptr, *d_cand_tab = nullptr, *d_cand_lab = nullptr;
+    double *d_part = nullptr;
+    uint8_t *d_maps = nullptr, *d_mapsT = nullptr; // dither path: per-candidate maps
+    // step state
+    uint8_t *d_cand = nullptr; uint32_t cand_cap = 0;
+    uint8_t *d_cand_sel = nullptr;
+    double *d_errs = nullptr, *d_errs_sel = nullptr;
+    double *d_inc_err = nullptr; // incumbent error
+    StepResult *d_last = nullptr;
+    double *d_scratch_err = nullptr;
+    uint8_t *d_dummy_cand = nullptr;
+    // k-means workspace
+    KmeansWork km{};
+
+    // cache keys
+    bool tables_valid = false, src_valid = false, inc_valid = false;
+    int pack_mode = -1, pack_sp = -1, pack_si = -1; bool pack_valid = false;
+    // pending step (split phase)
+    uint32_t pend_n = 0, pend_sp = 0, pend_si = 0, pend_method = 0; bool pend = false;
+
+    // timing
+    bool timing = false; hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double t_total_ms = 0.0; uint64_t t_launches = 0, t_cands = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> t_pending; std::vector<uint32_t> t_pending_n;
+};
+
+namespace {
+
+int32_t alloc_workspace(snesimage_ctx *c, uint32_t chunk) {
+    if (c->chunk_alloc >= chunk) return SNES_OK;
+    dfree(c->d_work); dfree(c->d_cand_tab); dfree(c->d_cand_lab); dfree(c->d_part); dfree(c->d_maps); dfree(c->d_mapsT);
+    HIPCHK(hipMalloc(&c->d_work, sizeof(float) * (size_t)c->G.cand_stride * chunk));
+    HIPCHK(hipMalloc(&c->d_cand_tab, sizeof(float) * 8 * (size_t)chunk));
+    HIPCHK(hipMalloc(&c->d_cand_lab, sizeof(float) * 3 * (size_t)chunk));
+    HIPCHK(hipMalloc(&c->d_part, sizeof(double) * (size_t)chunk * kMaxScales * 18));
+    if (c->dither) {
+        HIPCHK(hipMalloc(&c->d_maps, c->npx * (size_t)chunk));
+        HIPCHK(hipMalloc(&c->d_mapsT, c->npx * (size_t)chunk));
+    }
+    c->chunk_alloc = chunk;
+    return SNES_OK;
+}
+
+int32_t ensure_cand_capacity(snesimage_ctx *c, uint32_t n) {
+    if (c->cand_cap >= n) return SNES_OK;
+    dfree(c->d_cand); dfree(c->d_cand_sel); dfree(c->d_errs); dfree(c->d_errs_sel);
+    uint32_t cap = n < 64 ? 64 : n;
+    HIPCHK(hipMalloc(&c->d_cand, 3 * (size_t)cap));
+    HIPCHK(hipMalloc(&c->d_cand_sel, 3 * (size_t)cap));
+    HIPCHK(hipMalloc(&c->d_errs, sizeof(double) * cap));
+    HIPCHK(hipMalloc(&c->d_errs_sel, sizeof(double) * cap));
+    c->cand_cap = cap;
+    return SNES_OK;
+}
+
+int32_t ensure_tables(snesimage_ctx *c) {
+    if (c->tables_valid) return SNES_OK;
+    int n = c->ncol + 2;
+    hipLaunchKernelGGL(k_palette_tables, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->d_colors, c->ncol, c->d_eotf, c->d_pal_rgb8, c->d_pal_lin, c->d_pal_xyb);
+    if (c->perceptual)
+        hipLaunchKernelGGL(k_palette_lab, dim3((c->ncol + 63) / 64), dim3(64), 0, c->stream, c->d_pal_rgb8, c->ncol, c->d_lab_eotf, c->d_pal_lab);
+    HIPCHK(hipGetLastError());
+    c->tables_valid = true;
+    return SNES_OK;
+}
+
+// Source-side pyramid: img1, img1T, mu1, s11 at every scale (depends only on `original`).
+int32_t ensure_source(snesimage_ctx *c) {
+    if (c->src_valid) return SNES_OK;
+    CHECK(alloc_workspace(c, c->chunk));
+    const Geom &G = c->G;
+    hipLaunchKernelGGL(k_source_scale0, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, c->d_orig, c->d_eotf, (int)c->W, (int)c->H, c->d_lin0,
+                       c->d_img1, c->d_img1T);
+    if (G.nscales > 1) {
+        DownParams D{}; D.G = G; D.lin0 = c->d_lin0; D.work = c->d_img1; D.workT = c->d_img1T;
+        hipLaunchKernelGGL(k_downscale_chain<false>, dim3((G.W / 32) * ((G.H + 31) / 32), 1), dim3(256), 0, c->stream, D);
+    }
+    for (int s = 0; s < G.nscales; s++) {
+        HParams Hp{}; Hp.G = G; Hp.K = c->K; Hp.s = s; Hp.npairs = 3; Hp.ncol = c->ncol;
+        Hp.in1T = c->d_img1T + G.src_off[s]; Hp.in2T = c->d_img1T + G.src_off[s]; Hp.work = c->d_work;
+        int ppw = 256 / G.sh[s];
+        hipLaunchKernelGGL((k_hpass<false, false>), dim3((3 + ppw - 1) / ppw), dim3(256), 0, c->stream, Hp);
+        VParams Vp{}; Vp.G = G; Vp.K = c->K; Vp.s = s; Vp.npairs = 3; Vp.ncol = c->ncol;
+        Vp.img1 = c->d_img1 + G.src_off[s]; Vp.mu1_out = c->d_mu1 + G.src_off[s]; Vp.s11_out = c->d_s11 + G.src_off[s]; Vp.work = c->d_work;
+        int ppv = 256 / G.sw[s];
+        hipLaunchKernelGGL((k_vpass<false, true, false>), dim3((3 + ppv - 1) / ppv), dim3(256), 0, c->stream, Vp);
+    }
+    if (c->perceptual)
+        hipLaunchKernelGGL(k_pixel_lab, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, c->d_orig, c->d_lab_eotf, (int)c->W, (int)c->H, c->d_labpx, c->d_labpxT);
+    HIPCHK(hipGetLastError());
+    c->src_valid = true;
+    return SNES_OK;
+}
+
+int32_t run_prep(snesimage_ctx *c, int mode, int sp, int si) {
+    if (c->pack_valid && c->pack_mode == mode && (mode != 2 || (c->pack_sp == sp && c->pack_si == si))) return SNES_OK;
+    CHECK(ensure_tables(c));
+    if (c->perceptual) CHECK(ensure_source(c));
+    PrepParams P{};
+    P.orig = c->d_orig; P.tile_pal = c->d_tile_pal; P.pal_rgb8 = c->d_pal_rgb8; P.map = c->d_map; P.pack = c->d_pack; P.packT = c->d_packT;
+    P.labpx = c->d_labpx; P.pal_lab = c->d_pal_lab;
+    P.W = (int)c->W; P.H = (int)c->H; P.sub_size = (int)c->sub_size; P.ncol = c->ncol; P.mode = mode; P.sp = sp; P.si = si; P.perceptual = c->perceptual ? 1 : 0;
+    hipLaunchKernelGGL(k_prep, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, P);
+    HIPCHK(hipGetLastError());
+    c->pack_valid = true; c->pack_mode = mode; c->pack_sp = sp; c->pack_si = si;
+    return SNES_OK;
+}
+
+// Score nc candidates (device rgb5 list) given a prepared pack; errors -> d_errors[err_offset + k*err_stride].
+// slot_ci: colour index of the slot being replaced (dither path), or -1.
+int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double *d_errors, int err_stride, int err_offset, int sp, int si, uint8_t *d_maps_out) {
+    const Geom &G = c->G;
+    const int npairs = (int)nc * 3;
+    const bool use_maps = c->dither;
+    const uint32_t slot_ci = (sp >= 0) ? (uint32_t)(sp * (int)c->sub_size + si) : 0xffffffffu;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, c->stream)); }
+    hipLaunchKernelGGL(k_candidate_tables, dim3((nc + 63) / 64), dim3(64), 0, c->stream, d_rgb5, (int)nc, c->d_eotf, c->d_cand_tab);
+    hipLaunchKernelGGL(k_candidate_slot, dim3((nc + 63) / 64), dim3(64), 0, c->stream, c->d_cand_tab, (int)nc, slot_ci);
+    if (c->perceptual) hipLaunchKernelGGL(k_candidate_lab, dim3((nc + 63) / 64), dim3(64), 0, c->stream, c->d_cand_tab, (int)nc, c->d_lab_eotf, c->d_cand_lab);
+    if (use_maps) {
+        DitherParams Dp{};
+        Dp.orig = c->d_orig; Dp.tile_pal = c->d_tile_pal; Dp.pal_rgb8 = c->d_pal_rgb8; Dp.pal_lab = c->d_pal_lab; Dp.cand_tab = c->d_cand_tab; Dp.cand_lab = c->d_cand_lab;
+        Dp.lab_eotf = c->d_lab_eotf; Dp.maps = c->d_maps; Dp.mapsT = c->d_mapsT;
+        Dp.W = (int)c->W; Dp.H = (int)c->H; Dp.sub_size = (int)c->sub_size; Dp.ncol = c->ncol; Dp.slot_ci = slot_ci; Dp.perceptual = c->perceptual ? 1 : 0;
+        hipLaunchKernelGGL(k_dither, dim3(nc), dim3(128), 0, c->stream, Dp);
+        if (d_maps_out) HIPCHK(hipMemcpyAsync(d_maps_out, c->d_maps, c->npx * (size_t)nc, hipMemcpyDeviceToDevice, c->stream));
+    } else if (d_maps_out) {
+        MapsParams M{}; M.pack = c->d_pack; M.cand_tab = c->d_cand_tab; M.cand_lab = c->d_cand_lab; M.labpx = c->d_labpx; M.maps = d_maps_out;
+        M.npx = (int)c->npx; M.ncol = c->ncol; M.sub_size = (int)c->sub_size; M.si = si < 0 ? 0 : si; M.ncand = (int)nc; M.perceptual = c->perceptual ? 1 : 0;
+        hipLaunchKernelGGL(k_candidate_maps, dim3((unsigned)((c->npx + 255) / 256), nc), dim3(256), 0, c->stream, M);
+    }
+    if (G.nscales > 1) {
+        DownParams D{}; D.G = G; D.pack = c->d_pack; D.pal_lin = c->d_pal_lin; D.cand_tab = c->d_cand_tab; D.cand_lab = c->d_cand_lab; D.labpx = c->d_labpx;
+        D.work = c->d_work; D.ncol = c->ncol; D.perceptual = c->perceptual ? 1 : 0; D.use_maps = use_maps ? 1 : 0; D.maps = c->d_maps; D.tile_pal = c->d_tile_pal; D.sub_size = (int)c->sub_size;
+        hipLaunchKernelGGL(k_downscale_chain<true>, dim3((G.W / 32) * ((G.H + 31) / 32), nc), dim3(256), 0, c->stream, D);
+    }
+    for (int s = 0; s < G.nscales; s++) {
+        HParams Hp{}; Hp.G = G; Hp.K = c->K; Hp.s = s; Hp.npairs = npairs; Hp.ncol = c->ncol; Hp.perceptual = c->perceptual ? 1 : 0; Hp.use_maps = use_maps ? 1 : 0; Hp.sub_size = (int)c->sub_size;
+        Hp.packT = c->d_packT; Hp.pal_xyb = c->d_pal_xyb; Hp.cand_tab = c->d_cand_tab; Hp.cand_lab = c->d_cand_lab; Hp.labpxT = c->d_labpxT;
+        Hp.in1T = c->d_img1T + G.src_off[s]; Hp.in2T = nullptr; Hp.work = c->d_work; Hp.mapsT = c->d_mapsT; Hp.tile_pal = c->d_tile_pal;
+        int ppw = 256 / G.sh[s];
+        dim3 grid((npairs + ppw - 1) / ppw);
+        if (s == 0) {
+            if (c->perceptual && !use_maps) hipLaunchKernelGGL((k_hpass<true, true>), grid, dim3(256), 0, c->stream, Hp);
+            else hipLaunchKernelGGL((k_hpass<true, false>), grid, dim3(256), 0, c->stream, Hp);
+        } else hipLaunchKernelGGL((k_hpass<false, false>), grid, dim3(256), 0, c->stream, Hp);
+    }
+    for (int s = 0; s < G.nscales; s++) {
+        VParams Vp{}; Vp.G = G; Vp.K = c->K; Vp.s = s; Vp.npairs = npairs; Vp.ncol = c->ncol; Vp.perceptual = c->perceptual ? 1 : 0; Vp.use_maps = use_maps ? 1 : 0; Vp.sub_size = (int)c->sub_size;
+        Vp.pack = c->d_pack; Vp.pal_xyb = c->d_pal_xyb; Vp.cand_tab = c->d_cand_tab; Vp.cand_lab = c->d_cand_lab; Vp.labpx = c->d_labpx;
+        Vp.img1 = c->d_img1 + G.src_off[s]; Vp.mu1 = c->d_mu1 + G.src_off[s]; Vp.s11 = c->d_s11 + G.src_off[s]; Vp.work = c->d_work; Vp.part = c->d_part;
+        Vp.maps = c->d_maps; Vp.tile_pal = c->d_tile_pal;
+        int ppv = 256 / G.sw[s];
+        dim3 grid((npairs + ppv - 1) / ppv);
+        if (s == 0) {
+            if (c->perceptual && !use_maps) hipLaunchKernelGGL((k_vpass<true, false, true>), grid, dim3(256), 0, c->stream, Vp);
+            else hipLaunchKernelGGL((k_vpass<true, false, false>), grid, dim3(256), 0, c->stream, Vp);
+        } else hipLaunchKernelGGL((k_vpass<false, false, false>), grid, dim3(256), 0, c->stream, Vp);
+    }
+    hipLaunchKernelGGL(k_final_score, dim3((nc + 63) / 64), dim3(64), 0, c->stream, c->d_part, (int)nc, G, d_errors, err_stride, err_offset);
+    HIPCHK(hipGetLastError());
+    if (c->timing) { HIPCHK(hipEventRecord(e1, c->stream)); c->t_pending.emplace_back(e0, e1); c->t_pending_n.push_back(nc); }
+    return SNES_OK;
+}
+
+int32_t score_list(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t n, double *d_errors, int sp, int si, uint8_t *d_maps_out) {
+    CHECK(alloc_workspace(c, c->chunk));
+    CHECK(ensure_tables(c));
+    CHECK(ensure_source(c));
+    for (uint32_t c0 = 0; c0 < n; c0 += c->chunk) {
+        uint32_t nc = (n - c0 < c->chunk) ? (n - c0) : c->chunk;
+        CHECK(score_chunk(c, d_rgb5 + 3 * (size_t)c0, nc, d_errors, 1, (int)c0, sp, si, d_maps_out ? d_maps_out + (size_t)c0 * c->npx : nullptr));
+    }
+    return SNES_OK;
+}
+
+// optimize() on the current palette: no-dither -> argmin per pixel; dither -> serial error diffusion kernel
+int32_t do_optimize(snesimage_ctx *c) {
+    CHECK(ensure_tables(c));
+    if (!c->dither) {
+        c->pack_valid = false;
+        CHECK(run_prep(c, 0, -1, -1));
+    } else {
+        CHECK(alloc_workspace(c, c->chunk));
+        if (c->perceptual) CHECK(ensure_source(c));
+        // single pseudo-candidate whose slot index matches nothing
+        hipLaunchKernelGGL(k_candidate_tables, dim3(1), dim3(64), 0, c->stream, c->d_dummy_cand, 1, c->d_eotf, c->d_cand_tab);
+        hipLaunchKernelGGL(k_candidate_slot, dim3(1), dim3(64), 0, c->stream, c->d_cand_tab, 1, 0xffffffffu);
+        DitherParams Dp{};
+        Dp.orig = c->d_orig; Dp.tile_pal = c->d_tile_pal; Dp.pal_rgb8 = c->d_pal_rgb8; Dp.pal_lab = c->d_pal_lab; Dp.cand_tab = c->d_cand_tab; Dp.cand_lab = c->d_cand_lab;
+        Dp.lab_eotf = c->d_lab_eotf; Dp.maps = c->d_map; Dp.mapsT = c->d_mapsT;
+        Dp.W = (int)c->W; Dp.H = (int)c->H; Dp.sub_size = (int)c->sub_size; Dp.ncol = c->ncol; Dp.slot_ci = 0xffffffffu; Dp.perceptual = c->perceptual ? 1 : 0;
+        hipLaunchKernelGGL(k_dither, dim3(1), dim3(128), 0, c->stream, Dp);
+        HIPCHK(hipGetLastError());
+        c->pack_valid = false;
+    }
+    c->inc_valid = false;
+    return SNES_OK;
+}
+
+// error() of the stored palette_map -> d_out (device)
+int32_t do_error(snesimage_ctx *c, double *d_out) {
+    CHECK(alloc_workspace(c, c->chunk));
+    CHECK(ensure_tables(c));
+    CHECK(ensure_source(c));
+    bool saved_dither = c->dither;
+    c->dither = false; // evaluate the stored map: pack mode 1 carries every pixel's colour index
+    c->pack_valid = false;
+    int32_t rc = run_prep(c, 1, -1, -1);
+    if (rc == SNES_OK) rc = score_chunk(c, c->d_dummy_cand, 1, d_out, 1, 0, -1, -1, nullptr);
+    c->dither = saved_dither;
+    c->pack_valid = false;
+    return rc;
+}
+
+int32_t ensure_incumbent(snesimage_ctx *c) {
+    if (c->inc_valid) return SNES_OK;
+    CHECK(do_error(c, c->d_inc_err));
+    c->inc_valid = true;
+    return SNES_OK;
+}
+
+int32_t check_slot(snesimage_ctx *c, uint32_t palette, uint32_t index) {
+    if (!c) return fail(SNES_ERR_ARG, "null context");
+    if (palette >= c->sub_count || index >= c->sub_size) return fail(SNES_ERR_ARG, "palette slot out of range");
+    return SNES_OK;
+}
+
+int32_t set_device(snesimage_ctx *c) { HIPCHK(hipSetDevice(c->device)); return SNES_OK; }
+
+int32_t drain_timing(snesimage_ctx *c) {
+    for (size_t i = 0; i < c->t_pending.size(); i++) {
+        float ms = 0.0f;
+        HIPCHK(hipEventSynchronize(c->t_pending[i].second));
+        HIPCHK(hipEventElapsedTime(&ms, c->t_pending[i].first, c->t_pending[i].second));
+        c->t_total_ms += ms; c->t_launches += 1; c->t_cands += c->t_pending_n[i];
+        (void)hipEventDestroy(c->t_pending[i].first); (void)hipEventDestroy(c->t_pending[i].second);
+    }
+    c->t_pending.clear(); c->t_pending_n.clear();
+    return SNES_OK;
+}
+
+int32_t gen_candidates(snesimage_ctx *c, uint32_t method, uint32_t palette, uint32_t index, uint32_t channel, uint64_t seed, uint64_t step_id, uint32_t n) {
+    const uint64_t key = mix64(seed ^ (step_id * 0x9E3779B97F4A7C15ull) ^ 0xD1B54A32D192ED03ull);
+    hipLaunchKernelGGL(k_gen_candidates, dim3((n + 63) / 64), dim3(64), 0, c->stream, (int)method, (int)n, key, c->d_colors, (int)(palette * c->sub_size + index), (int)channel, c->d_cand);
+    HIPCHK(hipGetLastError());
+    return SNES_OK;
+}
+
+uint32_t method_count(uint32_t method, uint32_t n_random) { return method == SNES_METHOD_RANDOM ? (n_random ? n_random : 64u) : (method == SNES_METHOD_CHANNEL ? 32u : kNesColorCount); }
+
+int32_t commit(snesimage_ctx *c, const double *d_errors, uint32_t n, uint32_t method, uint32_t palette, uint32_t index) {
+    hipLaunchKernelGGL(k_commit, dim3(1), dim3(64), 0, c->stream, d_errors, (int)n, c->d_cand, c->d_colors, (int)(palette * c->sub_size + index), method == SNES_METHOD_NES ? 1 : 0, c->d_inc_err,
+                       c->d_last);
+    HIPCHK(hipGetLastError());
+    c->tables_valid = false;
+    c->pack_valid = false;
+    CHECK(do_optimize(c)); // lib.rs:237 / 281 / 325 (and :906)
+    c->inc_valid = true;   // k_commit left the committed state's error in d_inc_err (lib.rs:910 recomputes the same value)
+    return SNES_OK;
+}
+
+} // namespace
+
+#include "kmeans_host.inc"
+
+extern "C" {
+
+const char *snesimage_last_error(void) { return g_err.c_str(); }
+const char *snesimage_version(void) { return "snesimage_hip 0.1.0 (gfx950)"; }
+
+int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t sub_count, uint32_t sub_size, uint32_t flags, int32_t device, snesimage_ctx **out) {
+    if (!rgba || !out) return fail(SNES_ERR_ARG, "null pointer");
+    *out = nullptr;
+    if (w != 256) return fail(SNES_ERR_ARG, "image width must be 256 (tile stride is fixed at 32, lib.rs:58)");
+    if (h < 8 || h > 256 || (h & (h - 1)) != 0) return fail(SNES_ERR_ARG, "image height must be a power of two in [8,256]");
+    if (sub_count < 1 || sub_size < 1 || sub_count > 253 || sub_size > 253 || sub_count * sub_size > 253) return fail(SNES_ERR_ARG, "sub_count*sub_size must be in [1,253]");
+    if (device < 0) return fail(SNES_ERR_ARG, "device must be a HIP device ordinal >= 0 (this library has no CPU path)");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device >= ndev) return fail(SNES_ERR_ARG, "no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    snesimage_ctx *c = new snesimage_ctx();
+    c->device = device; c->W = w; c->H = h; c->sub_count = sub_count; c->sub_size = sub_size; c->flags = flags; c->ncol = (int)(sub_count * sub_size);
+    c->dither = flags & SNES_DITHER; c->perceptual = flags & SNES_PERCEPTUAL; c->nes = flags & SNES_NES;
+    c->npx = (size_t)w * h;
+    c->K = make_blur_constants();
+    if (const char *e = getenv("SNES_CHUNK")) { int v = atoi(e); if (v > 0) c->chunk = (uint32_t)v; }
+    Geom &G = c->G;
+    G.W = (int)w; G.H = (int)h; G.nscales = 0;
+    for (int s = 0; s < kMaxScales; s++) { if (((int)w >> s) < 8 || ((int)h >> s) < 8) break; G.sw[s] = (int)w >> s; G.sh[s] = (int)h >> s; G.nscales = s + 1; }
+    long long off = 0, soff = 0;
+    for (int s = 0; s < G.nscales; s++) {
+        long long N = (long long)G.sw[s] * G.sh[s];
+        G.src_off[s] = soff; soff += 3 * N;
+        if (s >= 1) { G.off_xyb[s] = off; off += 3 * N; G.off_xybT[s] = off; off += 3 * N; } else { G.off_xyb[s] = 0; G.off_xybT[s] = 0; }
+        G.off_hout[s] = off; off += 9 * N;
+    }
+    G.cand_stride = off;
+    c->src_floats = (size_t)soff;
+
+    int32_t rc = SNES_OK;
+    auto body = [&]() -> int32_t {
+        HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+        c->stream = c->own_stream;
+        HIPCHK(hipMalloc(&c->d_orig, c->npx * 4));
+        HIPCHK(hipMalloc(&c->d_tile_pal, 1024));
+        HIPCHK(hipMalloc(&c->d_colors, 3 * 256));
+        HIPCHK(hipMalloc(&c->d_map, c->npx));
+        HIPCHK(hipMalloc(&c->d_pack, c->npx * 8));
+        HIPCHK(hipMalloc(&c->d_packT, c->npx * 8));
+        HIPCHK(hipMalloc(&c->d_eotf, 256 * 4));
+        HIPCHK(hipMalloc(&c->d_lab_eotf, 256 * 4));
+        HIPCHK(hipMalloc(&c->d_pal_rgb8, 256 * 4));
+        HIPCHK(hipMalloc(&c->d_pal_lin, 256 * 3 * 4));
+        HIPCHK(hipMalloc(&c->d_pal_xyb, 256 * 3 * 4));
+        HIPCHK(hipMalloc(&c->d_pal_lab, 256 * 3 * 4));
+        HIPCHK(hipMalloc(&c->d_lin0, c->npx * 3 * 4));
+        HIPCHK(hipMalloc(&c->d_img1, c->src_floats * 4));
+        HIPCHK(hipMalloc(&c->d_img1T, c->src_floats * 4));
+        HIPCHK(hipMalloc(&c->d_mu1, c->src_floats * 4));
+        HIPCHK(hipMalloc(&c->d_s11, c->src_floats * 4));
+        if (c->perceptual) { HIPCHK(hipMalloc(&c->d_labpx, c->npx * 3 * 4)); HIPCHK(hipMalloc(&c->d_labpxT, c->npx * 3 * 4)); }
+        HIPCHK(hipMalloc(&c->d_inc_err, sizeof(double)));
+        HIPCHK(hipMalloc(&c->d_scratch_err, sizeof(double)));
+        HIPCHK(hipMalloc(&c->d_last, sizeof(StepResult)));
+        HIPCHK(hipMalloc(&c->d_dummy_cand, 64));
+        HIPCHK(hipMemsetAsync(c->d_dummy_cand, 0, 64, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_last, 0, sizeof(StepResult), c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_orig, rgba, c->npx * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_tile_pal, 0, 1024, c->stream));   // lib.rs:58
+        HIPCHK(hipMemsetAsync(c->d_colors, 0, 3 * 256, c->stream));  // lib.rs:756
+        HIPCHK(hipMemsetAsync(c->d_map, 0, c->npx, c->stream));      // lib.rs:60
+        c->h_orig.assign(rgba, rgba + c->npx * 4);
+        make_eotf_tables(c->h_eotf, c->h_lab_eotf);
+        HIPCHK(hipMemcpyAsync(c->d_eotf, c->h_eotf, sizeof(c->h_eotf), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_lab_eotf, c->h_lab_eotf, sizeof(c->h_lab_eotf), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        CHECK(ensure_cand_capacity(c, 64));
+        return SNES_OK;
+    };
+    rc = body();
+    if (rc != SNES_OK) { std::string keep = g_err; snesimage_destroy(c); g_err = keep; return rc; }
+    *out = c;
+    return SNES_OK;
+}
+
+void snesimage_destroy(snesimage_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)drain_timing(c);
+    dfree(c->d_orig); dfree(c->d_tile_pal); dfree(c->d_colors); dfree(c->d_map); dfree(c->d_pack); dfree(c->d_packT); dfree(c->d_eotf); dfree(c->d_lab_eotf);
+    dfree(c->d_pal_rgb8); dfree(c->d_pal_lin); dfree(c->d_pal_xyb); dfree(c->d_pal_lab); dfree(c->d_lin0); dfree(c->d_img1); dfree(c->d_img1T); dfree(c->d_mu1); dfree(c->d_s11);
+    dfree(c->d_labpx); dfree(c->d_labpxT); dfree(c->d_work); dfree(c->d_cand_tab); dfree(c->d_cand_lab); dfree(c->d_part); dfree(c->d_maps); dfree(c->d_mapsT);
+    dfree(c->d_cand); dfree(c->d_cand_sel); dfree(c->d_errs); dfree(c->d_errs_sel); dfree(c->d_inc_err); dfree(c->d_last); dfree(c->d_scratch_err); dfree(c->d_dummy_cand);
+    kmeans_free(c->km);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int32_t snesimage_set_stream(snesimage_ctx *c, void *s) {
+    if (!c) return fail(SNES_ERR_ARG, "null context");
+    CHECK(set_device(c));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return SNES_OK;
+}
+int32_t snesimage_sync(snesimage_ctx *c) {
+    if (!c) return fail(SNES_ERR_ARG, "null context");
+    CHECK(set_device(c));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SNES_OK;
+}
+int32_t snesimage_set_chunk(snesimage_ctx *c, uint32_t chunk) {
+    if (!c || chunk == 0 || chunk > 65535) return fail(SNES_ERR_ARG, "chunk must be in [1,65535]");
+    CHECK(set_device(c));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->chunk = chunk;
+    return SNES_OK;
+}
+
+int32_t snesimage_optimize(snesimage_ctx *c) {
+    if (!c) return fail(SNES_ERR_ARG, "null context");
+    CHECK(set_device(c));
+    CHECK(do_optimize(c));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SNES_OK;
+}
+
+int32_t snesimage_error(snesimage_ctx *c, double *out) {
+    if (!c || !out) return fail(SNES_ERR_ARG, "null pointer");
+    CHECK(set_device(c));
+    CHECK(do_error(c, c->d_scratch_err));
+    HIPCHK(hipMemcpyAsync(out, c->d_scratch_err, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SNES_OK;
+}
+
+int32_t snesimage_score_candidates_device(snesimage_ctx *c, uint32_t palette, uint32_t index, const uint8_t *d_rgb5, uint32_t n, double *d_errors, uint8_t *d_maps_out) {
+    CHECK(check_slot(c, palette, index));
+    if (!d_rgb5 || !d_errors) return fail(SNES_ERR_ARG, "null pointer");
+    if (n == 0) return SNES_OK;
+    CHECK(set_device(c));
+    if (!c->dither) CHECK(run_prep(c, 2, (int)palette, (int)index));
+    else CHECK(ensure_tables(c));
+    CHECK(score_list(c, d_rgb5, n, d_errors, (int)palette, (int)index, d_maps_out));
+    return SNES_OK;
+}
+
+int32_t snesimage_score_candidates(snesimage_ctx *c, uint32_t palette, uint32_t index, const uint8_t *rgb5, uint32_t n, double *errors) {
+    CHECK(check_slot(c, palette, index));
+    if (!rgb5 || !errors) return fail(SNES_ERR_ARG, "null pointer");
+    if (n == 0) return SNES_OK;
+    CHECK(set_device(c));
+    CHECK(ensure_cand_capacity(c, n));
+    HIPCHK(hipMemcpyAsync(c->d_cand_sel, rgb5, 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    CHECK(snesimage_score_candidates_device(c, palette, index, c->d_cand_sel, n, c->d_errs_sel, nullptr));
+    HIPCHK(hipMemcpyAsync(errors, c->d_errs_sel, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SNES_OK;
+}
+
+int32_t snesimage_step_async(snesimage_ctx *c, uint32_t method, uint32_t palette, uint32_t index, uint32_t channel, uint64_t seed, uint64_t step_id, uint32_t n_random) {
+    CHECK(check_slot(c, palette, index));
+    if (method > 2 || channel > 2) return fail(SNES_ERR_ARG, "bad method or channel");
+    CHECK(set_device(c));
+    const uint32_t n = method_count(method, n_random);
+    CHECK(ensure_cand_capacity(c, n));
+    if (method != SNES_METHOD_NES) CHECK(ensure_incumbent(c)); // lib.rs:199, 294 (nes: f64::MAX, lib.rs:250)
+    CHECK(gen_candidates(c, method, palette, index, channel, seed, step_id, n));
+    if (!c->dither) CHECK(run_prep(c, 2, (int)palette, (int)index));
+    CHECK(score_list(c, c->d_cand, n, c->d_errs, (int)palette, (int)index, nullptr));
+    CHECK(commit(c, c->d_errs, n, method, palette, index));
+    return SNES_OK;
+}
+
+int32_t snesimage_last_step(snesimage_ctx *c, double *best_error, uint8_t *best_rgb5, int32_t *best_k) {
+    if (!c) return fail(SNES_ERR_ARG, "null context");
+    CHECK(set_device(c));
+    StepResult r;
+    HIPCHK(hipMemcpyAsync(&r, c->d_last, sizeof(r), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (best_error) *best_error = r.error;
+    if (best_rgb5) { best_rgb5[0] = r.rgb5[0]; best_rgb5[1] = r.rgb5[1]; best_rgb5[2] = r.rgb5[2]; }
+    if (best_k) *best_k = r.best_k;
+    return SNES_OK;
+}
+
+int32_t snesimage_step(snesimage_ctx *c, uint32_t method, uint32_t palette, uint32_t index, uint32_t channel, uint64_t seed, uint64_t step_id, uint32_t n_random, double *best_error,
+                       uint8_t *best_rgb5) {
+    CHECK(snesimage_step_async(c, method, palette, index, channel, seed, step_id, n_random));
+    return snesimage_last_step(c, best_error, best_rgb5, nullptr);
+}
+
+int32_t snesimage_step_begin(snesimage_ctx *c, uint32_t method, uint32_t palette, uint32_t index, uint32_t channel, uint64_t seed, uint64_t step_id, uint32_t n_total, uint32_t shard_rank,
+                             uint32_t shard_count, double *d_errors) {
+    CHECK(check_slot(c, palette, index));
+    if (method > 2 || channel > 2 || shard_count == 0 || shard_rank >= shard_count || !d_errors) return fail(SNES_ERR_ARG, "bad step_begin arguments");
+    CHECK(set_device(c));
+    const uint32_t n = method_count(method, n_total);
+    CHECK(ensure_cand_capacity(c, n));
+    if (method != SNES_METHOD_NES) CHECK(ensure_incumbent(c));
+    CHECK(gen_candidates(c, method, palette, index, channel, seed, step_id, n));
+    const uint32_t n_own = (n > shard_rank) ? (n - shard_rank + shard_count - 1) / shard_count : 0;
+    hipLaunchKernelGGL(k_shard_select, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->d_cand, (int)n, (int)shard_rank, (int)shard_count, c->d_cand_sel, d_errors);
+    HIPCHK(hipGetLastError());
+    if (n_own) {
+        if (!c->dither) CHECK(run_prep(c, 2, (int)palette, (int)index));
+        CHECK(alloc_workspace(c, c->chunk));
+        CHECK(ensure_tables(c));
+        CHECK(ensure_source(c));
+        for (uint32_t c0 = 0; c0 < n_own; c0 += c->chunk) {
+            uint32_t nc = (n_own - c0 < c->chunk) ? (n_own - c0) : c->chunk;
+            // candidate j of the shard is global candidate shard_rank + j*shard_count
+            CHECK(score_chunk(c, c->d_cand_sel + 3 * (size_t)c0, nc, d_errors, (int)shard_count, (int)(shard_rank + c0 * shard_count), (int)palette, (int)index, nullptr));
+        }
+    }
+    c->pend = true; c->pend_n = n; c->pend_sp = palette; c->pend_si = index; c->pend_method = method;
+    return SNES_OK;
+}
+
+int32_t snesimage_step_commit(snesimage_ctx *c, const double *d_errors) {
+    if (!c || !d_errors) return fail(SNES_ERR_ARG, "null pointer");
+    if (!c->pend) return fail(SNES_ERR_STATE, "step_commit without step_begin");
+    CHECK(set_device(c));
+    c->pend = false;
+    return commit(c, d_errors, c->pend_n, c->pend_method, c->pend_sp, c->pend_si);
+}
+
+int32_t snesimage_get_tile_palettes(snesimage_ctx *c, uint8_t *out) {
+    if (!c || !out) return fail(SNES_ERR_ARG, "null pointer");
+    CHECK(set_device(c));
+    HIPCHK(hipMemcpyAsync(out, c->d_tile_pal, 1024, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SNES_OK;
+}
+int32_t snesimage_set_tile_palettes(snesimage_ctx *c, const uint8_t *in) {
+    if (!c || !in) return fail(SNES_ERR_ARG, "null pointer");
+    for (int i = 0; i < 1024; i++) if (in[i] >= c->sub_count) return fail(SNES_ERR_ARG, "tile palette index out of range");
+    CHECK(set_device(c));
+    HIPCHK(hipMemcpyAsync(c->d_tile_pal, in, 1024, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->pack_valid = false; c->inc_valid = false;
+    return SNES_OK;
+}
+int32_t snesimage_get_palette_rgb5(snesimage_ctx *c, uint8_t *out) {
+    if (!c || !out) return fail(SNES_ERR_ARG, "null pointer");
+    CHECK(set_device(c));
+    HIPCHK(hipMemcpyAsync(out, c->d_colors, 3 * (size_t)c->ncol, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SNES_OK;
+}
+int32_t snesimage_set_palette_rgb5(snesimage_ctx *c, const uint8_t *in) {
+    if (!c || !in) return fail(SNES_ERR_ARG, "null pointer");
+    CHECK(set_device(c));
+    HIPCHK(hipMemcpyAsync(c->d_colors, in, 3 * (size_t)c->ncol, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->tables_valid = false; c->pack_valid = false; c->inc_valid = false;
+    return SNES_OK;
+}
+int32_t snesimage_get_palette_u16(snesimage_ctx *c, uint16_t *out) {
+    if (!c || !out) return fail(SNES_ERR_ARG, "null pointer");
+    std::vector<uint8_t> raw(3 * (size_t)c->ncol);
+    CHECK(snesimage_get_palette_rgb5(c, raw.data()));
+    for (int i = 0; i < c->ncol; i++) out[i] = rgb5_as_u16(raw[3 * i], raw[3 * i + 1], raw[3 * i + 2]);
+    return SNES_OK;
+}
+int32_t snesimage_get_palette_map(snesimage_ctx *c, uint8_t *out) {
+    if (!c || !out) return fail(SNES_ERR_ARG, "null pointer");
+    CHECK(set_device(c));
+    HIPCHK(hipMemcpyAsync(out, c->d_map, c->npx, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SNES_OK;
+}
+int32_t snesimage_set_palette_map(snesimage_ctx *c, const uint8_t *in) {
+    if (!c || !in) return fail(SNES_ERR_ARG, "null pointer");
+    for (size_t i = 0; i < c->npx; i++) if (in[i] >= c->sub_size) return fail(SNES_ERR_ARG, "palette_map entry out of range");
+    CHECK(set_device(c));
+    HIPCHK(hipMemcpyAsync(c->d_map, in, c->npx, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->pack_valid = false; c->inc_valid = false;
+    return SNES_OK;
+}
+
+// lib.rs:550-577 (host-side reconstruction from the device state; not on the hot path)
+int32_t snesimage_as_rgba(snesimage_ctx *c, uint8_t *out) {
+    if (!c || !out) return fail(SNES_ERR_ARG, "null pointer");
+    std::vector<uint8_t> map(c->npx), tp(1024), col(3 * (size_t)c->ncol), orig(c->npx * 4);
+    CHECK(snesimage_get_palette_map(c, map.data()));
+    CHECK(snesimage_get_tile_palettes(c, tp.data()));
+    CHECK(snesimage_get_palette_rgb5(c, col.data()));
+    HIPCHK(hipMemcpy(orig.data(), c->d_orig, c->npx * 4, hipMemcpyDeviceToHost));
+    memset(out, 0, c->npx * 4);
+    for (uint32_t y = 0; y < c->H; y++)
+        for (uint32_t x = 0; x < c->W; x++) {
+            size_t px = (size_t)y * c->W + x;
+            if (orig[4 * px + 3] == 0) continue;
+            size_t ci = (size_t)tp[(y / 8) * 32 + (x / 8)] * c->sub_size + map[px];
+            uint32_t v = rgb5_to_rgb8(col[3 * ci], col[3 * ci + 1], col[3 * ci + 2]);
+            out[4 * px] = v & 0xff; out[4 * px + 1] = (v >> 8) & 0xff; out[4 * px + 2] = (v >> 16) & 0xff; out[4 * px + 3] = 255;
+        }
+    return SNES_OK;
+}
+
+// lib.rs:579-625 + :1002; serde_json (no preserve_order) emits keys sorted: palette, tile_palettes, tiles
+int64_t snesimage_as_json(snesimage_ctx *c, char *out, int64_t cap) {
+    if (!c) return fail(SNES_ERR_ARG, "null context");
+    std::vector<uint8_t> map(c->npx), tp(1024), col(3 * (size_t)c->ncol), orig(c->npx * 4);
+    if (snesimage_get_palette_map(c, map.data()) || snesimage_get_tile_palettes(c, tp.data()) || snesimage_get_palette_rgb5(c, col.data())) return SNES_ERR_HIP;
+    if (hipMemcpy(orig.data(), c->d_orig, c->npx * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(SNES_ERR_HIP, "hipMemcpy failed");
+    const uint32_t wt = c->W / 8, ht = c->H / 8;
+    std::string s = "{\"palette\":[";
+    for (uint32_t p = 0; p < c->sub_count; p++)
+        for (uint32_t i = 0; i < 16; i++) {
+            unsigned v = 0;
+            if (i != 0 && i <= c->sub_size) { size_t k = (size_t)p * c->sub_size + i - 1; v = rgb5_as_u16(col[3 * k], col[3 * k + 1], col[3 * k + 2]); }
+            if (p || i) s += ',';
+            s += std::to_string(v);
+        }
+    s += "],\"tile_palettes\":[";
+    for (uint32_t t = 0; t < wt * ht; t++) { if (t) s += ','; s += std::to_string((unsigned)tp[t]); }
+    s += "],\"tiles\":[";
+    for (uint32_t ty = 0; ty < ht; ty++)
+        for (uint32_t tx = 0; tx < wt; tx++) {
+            if (ty || tx) s += ',';
+            s += '[';
+            for (uint32_t y = 0; y < 8; y++)
+                for (uint32_t x = 0; x < 8; x++) {
+                    size_t px = (size_t)(ty * 8 + y) * c->W + (tx * 8 + x);
+                    unsigned v = orig[4 * px + 3] == 0 ? 0u : (unsigned)(uint8_t)(map[px] + 1);
+                    if (x || y) s += ',';
+                    s += std::to_string(v);
+                }
+            s += ']';
+        }
+    s += "]}";
+    int64_t need = (int64_t)s.size() + 1;
+    if (out && cap > 0) { int64_t m = cap - 1 < (int64_t)s.size() ? cap - 1 : (int64_t)s.size(); memcpy(out, s.data(), (size_t)m); out[m] = 0; }
+    return need;
+}
+
+void snesimage_random_candidates(uint64_t seed, uint64_t step_id, uint32_t n, uint8_t *rgb5) {
+    const uint64_t key = mix64(seed ^ (step_id * 0x9E3779B97F4A7C15ull) ^ 0xD1B54A32D192ED03ull);
+    for (uint32_t k = 0; k < n; k++) {
+        uint64_t z = mix64(key + ((uint64_t)k + 1) * 0x9E3779B97F4A7C15ull);
+        rgb5[3 * k] = (uint8_t)(z & 31); rgb5[3 * k + 1] = (uint8_t)((z >> 5) & 31); rgb5[3 * k + 2] = (uint8_t)((z >> 10) & 31);
+    }
+}
+
+// lib.rs:890, 917-932
+void snesimage_schedule_next(uint32_t sub_count, uint32_t sub_size, int32_t nes, uint32_t *palette, uint32_t *index, uint32_t *channel, uint32_t *step, uint32_t *method) {
+    const bool random = (*step % 5) < 4;
+    if (method) *method = nes ? SNES_METHOD_NES : (random ? SNES_METHOD_RANDOM : SNES_METHOD_CHANNEL);
+    *channel += 1;
+    if (*channel == 3 || random) {
+        *channel = 0; *index += 1;
+        if (*index == sub_size) { *index = 0; *palette += 1; if (*palette == sub_count) { *palette = 0; *step += 1; } }
+    }
+}
+
+int32_t snesimage_initialize_tiles(snesimage_ctx *c) {
+    if (!c) return fail(SNES_ERR_ARG, "null context");
+    CHECK(set_device(c));
+    return kmeans_initialize_tiles(c);
+}
+int32_t snesimage_recalculate_palettes(snesimage_ctx *c) {
+    if (!c) return fail(SNES_ERR_ARG, "null context");
+    CHECK(set_device(c));
+    return kmeans_recalculate_palettes(c);
+}
+
+int32_t snesimage_timing_enable(snesimage_ctx *c, int32_t on) {
+    if (!c) return fail(SNES_ERR_ARG, "null context");
+    CHECK(set_device(c));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    CHECK(drain_timing(c));
+    c->timing = on != 0; c->t_total_ms = 0.0; c->t_launches = 0; c->t_cands = 0;
+    return SNES_OK;
+}
+int32_t snesimage_timing_read(snesimage_ctx *c, double *total_ms, uint64_t *launches, uint64_t *candidates) {
+    if (!c) return fail(SNES_ERR_ARG, "null context");
+    CHECK(set_device(c));
+    CHECK(drain_timing(c));
+    if (total_ms) *total_ms = c->t_total_ms;
+    if (launches) *launches = c->t_launches;
+    if (candidates) *candidates = c->t_cands;
+    return SNES_OK;
+}
+
+int32_t snesimage_debug_math(int32_t device, int32_t op, const float *x, const float *y, uint32_t n, float *out) {
+    if (!x || !out || n == 0) return fail(SNES_ERR_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(device));
+    const uint32_t per_in = (op == 5 || op == 6) ? 3 : 1, per_out = (op == 6) ? 3 : 1;
+    float *dx = nullptr, *dy = nullptr, *dout = nullptr, *dlut = nullptr;
+    HIPCHK(hipMalloc(&dx, sizeof(float) * n * per_in));
+    HIPCHK(hipMalloc(&dy, sizeof(float) * n * per_in));
+    HIPCHK(hipMalloc(&dout, sizeof(float) * n * per_out));
+    HIPCHK(hipMalloc(&dlut, sizeof(float) * 256));
+    float e1[256], e2[256];
+    make_eotf_tables(e1, e2);
+    HIPCHK(hipMemcpy(dlut, e2, sizeof(e2), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dx, x, sizeof(float) * n * per_in, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dy, y ? y : x, sizeof(float) * n * per_in, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, 0, op, dx, dy, (int)n, dlut, dout);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, dout, sizeof(float) * n * per_out, hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout); (void)hipFree(dlut);
+    return SNES_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,136 @@
+// snesimage_amd/csrc/color.hpp — colour primitives of the hot path, host + device.
+// Reference: /root/reference/src/lib.rs:628-795 (SnesColor, NES table, nearest-entry argmin) and
+// :1080-1100 (distances); third-party arithmetic per SURVEY App. A (palette 0.7.6, yuvxyb 0.4.2).
+#pragma once
+#include "dmath.hpp"
+
+namespace snes {
+
+// SnesColor::as_rgba, lib.rs:662-669: `v*8 + v/4` in u8 arithmetic (wraps for v >= 32, quirk Q3).
+SNES_HD uint32_t expand5(uint32_t v) { return ((v * 8u) + (v / 4u)) & 0xffu; }
+// raw 5-bit triple -> packed 0x00BBGGRR of the 8-bit expansion
+SNES_HD uint32_t rgb5_to_rgb8(uint32_t r, uint32_t g, uint32_t b) { return expand5(r) | (expand5(g) << 8) | (expand5(b) << 16); }
+// SnesColor::as_u16, lib.rs:679-681
+SNES_HD uint16_t rgb5_as_u16(uint32_t r, uint32_t g, uint32_t b) { return (uint16_t)(r + (g << 5) + (b << 10)); }
+
+// color_distance_red_mean (lib.rs:1080-1088) without the sqrt, times 512: every term is an exact
+// integer (max 299,505,150 < 2^31), and sqrt is strictly monotone, so ordering by this key equals
+// ordering by the reference's f64 distance, ties included.
+SNES_HD uint32_t red_mean_key(uint32_t c1, uint32_t c2) {
+    int r1 = c1 & 0xff, r2 = c2 & 0xff;
+    int dr = r1 - r2, dg = (int)((c1 >> 8) & 0xff) - (int)((c2 >> 8) & 0xff), db = (int)((c1 >> 16) & 0xff) - (int)((c2 >> 16) & 0xff);
+    int rs = r1 + r2;
+    return (uint32_t)((1024 + rs) * dr * dr + 2048 * dg * dg + (1534 - rs) * db * db);
+}
+
+// NES table, lib.rs:685-745
+__device__ __constant__ const uint8_t kNesTableDev[56][3] = {
+    {13, 13, 13}, {0, 2, 16},   {3, 0, 17},   {7, 0, 15},   {10, 0, 10},  {11, 0, 3},   {9, 2, 0},
+    {7, 3, 0},    {4, 6, 0},    {0, 7, 0},    {0, 8, 0},    {0, 7, 4},    {0, 5, 10},   {0, 0, 0},
+    {23, 23, 23}, {3, 10, 24},  {9, 6, 28},   {14, 4, 26},  {18, 3, 21},  {19, 5, 11},  {19, 6, 0},
+    {15, 9, 0},   {11, 12, 0},  {4, 14, 0},   {0, 15, 0},   {0, 14, 8},   {0, 13, 17},  {0, 0, 0},
+    {31, 31, 31}, {13, 20, 31}, {17, 19, 31}, {22, 16, 31}, {27, 14, 31}, {28, 14, 23}, {28, 17, 13},
+    {26, 19, 5},  {22, 21, 1},  {15, 24, 2},  {10, 25, 8},  {8, 25, 16},  {8, 24, 24},  {9, 9, 9},
+    {31, 31, 31}, {25, 29, 31}, {27, 27, 31}, {29, 27, 31}, {31, 26, 31}, {31, 26, 30}, {31, 27, 25},
+    {31, 28, 22}, {30, 30, 21}, {27, 31, 21}, {25, 31, 23}, {24, 31, 26}, {24, 30, 30}, {23, 24, 23}};
+static const uint8_t kNesTableHost[56][3] = {
+    {13, 13, 13}, {0, 2, 16},   {3, 0, 17},   {7, 0, 15},   {10, 0, 10},  {11, 0, 3},   {9, 2, 0},
+    {7, 3, 0},    {4, 6, 0},    {0, 7, 0},    {0, 8, 0},    {0, 7, 4},    {0, 5, 10},   {0, 0, 0},
+    {23, 23, 23}, {3, 10, 24},  {9, 6, 28},   {14, 4, 26},  {18, 3, 21},  {19, 5, 11},  {19, 6, 0},
+    {15, 9, 0},   {11, 12, 0},  {4, 14, 0},   {0, 15, 0},   {0, 14, 8},   {0, 13, 17},  {0, 0, 0},
+    {31, 31, 31}, {13, 20, 31}, {17, 19, 31}, {22, 16, 31}, {27, 14, 31}, {28, 14, 23}, {28, 17, 13},
+    {26, 19, 5},  {22, 21, 1},  {15, 24, 2},  {10, 25, 8},  {8, 25, 16},  {8, 24, 24},  {9, 9, 9},
+    {31, 31, 31}, {25, 29, 31}, {27, 27, 31}, {29, 27, 31}, {31, 26, 31}, {31, 26, 30}, {31, 27, 25},
+    {31, 28, 22}, {30, 30, 21}, {27, 31, 21}, {25, 31, 23}, {24, 31, 26}, {24, 30, 30}, {23, 24, 23}};
+constexpr uint32_t kNesColorCount = 56;
+
+// ---- palette 0.7.6 Lab pipeline, f32 ----------------------------------------------------------
+struct Lab { float l, a, b; };
+
+SNES_HD float lab_f(float c) {
+    const float epsilon = (float)(6.0 / 29.0) * (float)(6.0 / 29.0) * (float)(6.0 / 29.0);
+    const float kappa = (float)(841.0 / 108.0);
+    const float delta = (float)(4.0 / 29.0);
+    return c > epsilon ? d_cbrtf(c) : (kappa * c) + delta;
+}
+// lin_* : linear-light components from the 256-entry sRGB table (built on the host, see capi)
+SNES_HD Lab linear_to_lab(float r, float g, float b) {
+    float x = (r * 0.4124564f) + (g * 0.3575761f) + (b * 0.1804375f);
+    float y = (r * 0.2126729f) + (g * 0.7151522f) + (b * 0.0721750f);
+    float z = (r * 0.0193339f) + (g * 0.1191920f) + (b * 0.9503041f);
+    x = x / 0.95047f; y = y / 1.0f; z = z / 1.08883f;
+    float fx = lab_f(x), fy = lab_f(y), fz = lab_f(z);
+    Lab o; o.l = (fy * 116.0f) - 16.0f; o.a = (fx - fy) * 500.0f; o.b = (fy - fz) * 200.0f;
+    return o;
+}
+
+SNES_HD float ciede_hprime(float b, float ap) {
+    if (b == 0.0f && ap == 0.0f) return 0.0f;
+    float r = d_atan2f(b, ap) * (float)(180.0 / 3.14159265358979323846);
+    return r < 0.0f ? r + 360.0f : r;
+}
+// palette::color_difference::Ciede2000 for Lab<_, f32>, kL = kC = kH = 1
+SNES_HD float ciede2000(Lab c1, Lab c2) {
+    const float pi_over_180 = (float)(3.14159265358979323846 / 180.0);
+    const float p25_7 = 6103515625.0f;
+    float ch1 = sqrtf(c1.a * c1.a + c1.b * c1.b), ch2 = sqrtf(c2.a * c2.a + c2.b * c2.b);
+    float c_bar = (ch1 + ch2) / 2.0f;
+    float cb2 = c_bar * c_bar, cb4 = cb2 * cb2;
+    float cb7 = (c_bar * cb2) * cb4;
+    float g = 0.5f * (1.0f - sqrtf(cb7 / (cb7 + p25_7)));
+    float a1p = c1.a * (1.0f + g), a2p = c2.a * (1.0f + g);
+    float c1p = sqrtf(a1p * a1p + c1.b * c1.b), c2p = sqrtf(a2p * a2p + c2.b * c2.b);
+    float h1p = ciede_hprime(c1.b, a1p), h2p = ciede_hprime(c2.b, a2p);
+    float hd = h2p - h1p, had = fabsf(hd);
+    bool zc = (c1p == 0.0f) || (c2p == 0.0f);
+    float dh;
+    if (zc) dh = 0.0f;
+    else if (had <= 180.0f) dh = hd;
+    else if (h2p <= h1p) dh = hd + 360.0f;
+    else dh = hd - 360.0f;
+    float dH = 2.0f * sqrtf(c1p * c2p) * d_sinf(dh / 2.0f * pi_over_180);
+    float hs = h1p + h2p;
+    float hbar;
+    if (zc) hbar = hs;
+    else if (had > 180.0f) hbar = (hs + 360.0f) / 2.0f;
+    else hbar = hs / 2.0f;
+    float lbar = (c1.l + c2.l) / 2.0f;
+    float cbp = (c1p + c2p) / 2.0f;
+    float t = 1.0f - 0.17f * d_cosf((hbar - 30.0f) * pi_over_180) + 0.24f * d_cosf((hbar * 2.0f) * pi_over_180)
+              + 0.32f * d_cosf((hbar * 3.0f + 6.0f) * pi_over_180) - 0.20f * d_cosf((hbar * 4.0f - 63.0f) * pi_over_180);
+    float lm = lbar - 50.0f;
+    float sl = 1.0f + ((0.015f * lm * lm) / sqrtf(lm * lm + 20.0f));
+    float sc = 1.0f + 0.045f * cbp;
+    float sh = 1.0f + 0.015f * cbp * t;
+    float hb = (hbar - 275.0f) / 25.0f;
+    float dtheta = 30.0f * d_expf_neg(-(hb * hb));
+    float cp2 = cbp * cbp, cp4 = cp2 * cp2;
+    float cp7 = (cbp * cp2) * cp4;
+    float rc = 2.0f * sqrtf(cp7 / (cp7 + p25_7));
+    float rt = -rc * d_sinf(2.0f * dtheta * pi_over_180);
+    float dl = c2.l - c1.l, dc = c2p - c1p;
+    float tl = dl / sl, tc = dc / sc, th = dH / sh;
+    return sqrtf(tl * tl + tc * tc + th * th + (rt * dc * dH) / (sc * sh));
+}
+
+// ---- yuvxyb 0.4.2 linear RGB -> XYB, then ssimulacra2's make_positive_xyb ----------------------
+SNES_HD void linear_to_positive_xyb(float r, float g, float b, float &X, float &Y, float &B) {
+    const float m02 = 0.078f, m00 = 0.30f, m01 = 1.0f - m02 - m00;
+    const float m12 = 0.078f, m10 = 0.23f, m11 = 1.0f - m12 - m10;
+    const float m20 = 0.24342268924547819f, m21 = 0.20476744424496821f, m22 = 1.0f - m20 - m21;
+    const float b0 = 0.0037930732552754493f;
+    const float b0_root = 0.1559542025327239180319220163705f;
+    float a0 = fmaf(m00, r, fmaf(m01, g, fmaf(m02, b, b0)));
+    float a1 = fmaf(m10, r, fmaf(m11, g, fmaf(m12, b, b0)));
+    float a2 = fmaf(m20, r, fmaf(m21, g, fmaf(m22, b, b0)));
+    if (a0 < 0.0f) a0 = 0.0f;
+    if (a1 < 0.0f) a1 = 0.0f;
+    if (a2 < 0.0f) a2 = 0.0f;
+    a0 = d_cbrtf(a0) - b0_root; a1 = d_cbrtf(a1) - b0_root; a2 = d_cbrtf(a2) - b0_root;
+    float x = 0.5f * (a0 - a1), y = 0.5f * (a0 + a1);
+    B = (a2 - y) + 0.55f;
+    X = fmaf(x, 14.0f, 0.42f);
+    Y = y + 0.01f;
+}
+
+} // namespace snes

@@ -1,0 +1,326 @@
+// snesimage_amd/csrc/kernels_opt.hpp — the kernels around the scoring pipeline: Lab tables for
+// --perceptual-palettes, the Floyd-Steinberg remap (--dither), candidate generation and the
+// commit rule of the optimizer step, and the k-means initialisers.
+#pragma once
+#include "kernels.hpp"
+
+namespace snes {
+
+// ---- Lab tables (palette 0.7.6 pipeline; lab_eotf = Srgb::into_linear on v/255) -----------------
+__global__ void k_palette_lab(const uint32_t *__restrict__ pal_rgb8, int ncol, const float *__restrict__ lab_eotf, float *__restrict__ pal_lab) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncol) return;
+    uint32_t c = pal_rgb8[i];
+    Lab l = linear_to_lab(lab_eotf[c & 0xff], lab_eotf[(c >> 8) & 0xff], lab_eotf[(c >> 16) & 0xff]);
+    pal_lab[3 * i] = l.l; pal_lab[3 * i + 1] = l.a; pal_lab[3 * i + 2] = l.b;
+}
+__global__ void k_candidate_lab(const float *__restrict__ cand_tab, int n, const float *__restrict__ lab_eotf, float *__restrict__ cand_lab) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t c = __float_as_uint(cand_tab[8 * (size_t)k + 6]);
+    Lab l = linear_to_lab(lab_eotf[c & 0xff], lab_eotf[(c >> 8) & 0xff], lab_eotf[(c >> 16) & 0xff]);
+    cand_lab[3 * k] = l.l; cand_lab[3 * k + 1] = l.a; cand_lab[3 * k + 2] = l.b;
+}
+__global__ void k_candidate_slot(float *__restrict__ cand_tab, int n, uint32_t slot_ci) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) cand_tab[8 * (size_t)k + 7] = __uint_as_float(slot_ci);
+}
+__global__ __launch_bounds__(256) void k_pixel_lab(const uint8_t *__restrict__ orig, const float *__restrict__ lab_eotf, int W, int H, float *__restrict__ labpx, float *__restrict__ labpxT) {
+    int px = blockIdx.x * blockDim.x + threadIdx.x;
+    if (px >= W * H) return;
+    int x = px % W, y = px / W;
+    uint32_t o = reinterpret_cast<const uint32_t *>(orig)[px];
+    Lab l = linear_to_lab(lab_eotf[o & 0xff], lab_eotf[(o >> 8) & 0xff], lab_eotf[(o >> 16) & 0xff]);
+    labpx[3 * (size_t)px] = l.l; labpx[3 * (size_t)px + 1] = l.a; labpx[3 * (size_t)px + 2] = l.b;
+    size_t pt = (size_t)x * H + y;
+    labpxT[3 * pt] = l.l; labpxT[3 * pt + 1] = l.a; labpxT[3 * pt + 2] = l.b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// optimize() with Floyd-Steinberg error diffusion (lib.rs:425-501), one block per candidate.
+// The raster scan's dependency (x-1,y), (x-1..x+1,y-1) leaves the anti-diagonals t = x + 2y free:
+// thread j owns rows j and j+128, so it works through 512 consecutive pixels starting at step 2j.
+// Diffused error is gathered, not scattered: e(x,y) = (((0 + v(x-1,y-1)*0.8*w3) + v(x,y-1)*0.8*w2)
+// + v(x+1,y-1)*0.8*w1) + v(x-1,y)*0.8*w0 — the order in which the reference's `+=` reach the
+// pixel — in binary64, so the rounding is the reference's.  v of the row above comes from a
+// 4-deep LDS ring written by the neighbouring thread 1..3 steps earlier.
+// ------------------------------------------------------------------------------------------------
+struct DitherParams {
+    const uint8_t *orig; const uint8_t *tile_pal; const uint32_t *pal_rgb8; const float *pal_lab; const float *cand_tab; const float *cand_lab; const float *lab_eotf;
+    uint8_t *maps, *mapsT;
+    int W, H, sub_size, ncol; uint32_t slot_ci; int perceptual;
+};
+
+__global__ __launch_bounds__(128) void k_dither(DitherParams P) {
+    __shared__ uint32_t s_rgb8[256];
+    __shared__ float s_lab[256 * 3];
+    __shared__ float s_eotf[256];
+    __shared__ double ring[128][4][3];
+    const int j = threadIdx.x;
+    const int cand = blockIdx.x;
+    const int W = P.W, H = P.H;
+    for (int i = j; i < P.ncol; i += 128) {
+        s_rgb8[i] = P.pal_rgb8[i];
+        if (P.perceptual) { s_lab[3 * i] = P.pal_lab[3 * i]; s_lab[3 * i + 1] = P.pal_lab[3 * i + 1]; s_lab[3 * i + 2] = P.pal_lab[3 * i + 2]; }
+    }
+    if (P.perceptual) for (int i = j; i < 256; i += 128) s_eotf[i] = P.lab_eotf[i];
+    __syncthreads();
+    if (j == 0 && P.slot_ci < (uint32_t)P.ncol) {
+        s_rgb8[P.slot_ci] = __float_as_uint(P.cand_tab[8 * (size_t)cand + 6]);
+        if (P.perceptual) { s_lab[3 * P.slot_ci] = P.cand_lab[3 * cand]; s_lab[3 * P.slot_ci + 1] = P.cand_lab[3 * cand + 1]; s_lab[3 * P.slot_ci + 2] = P.cand_lab[3 * cand + 2]; }
+    }
+    for (int q = 0; q < 4; q++) { ring[j][q][0] = 0.0; ring[j][q][1] = 0.0; ring[j][q][2] = 0.0; }
+    __syncthreads();
+    const double w0 = 7.0 / 16.0, w1 = 3.0 / 16.0, w2 = 5.0 / 16.0, w3 = 1.0 / 16.0, mult = 0.8;
+    const int rows_per_thread = (H + 127) / 128; // 1 or 2 (H <= 256)
+    const int total_steps = 2 * 127 + rows_per_thread * W;
+    double left[3] = {0.0, 0.0, 0.0}; // v(x-1, y) of this thread's current row
+    uint8_t *map = P.maps + (size_t)cand * W * H;
+    uint8_t *mapT = P.mapsT ? P.mapsT + (size_t)cand * W * H : nullptr;
+    const int up = (j + 127) & 127; // thread owning row y-1
+    for (int t = 0; t < total_steps; t++) {
+        const int local = t - 2 * j; // position in this thread's 512-pixel stream
+        double v[3] = {0.0, 0.0, 0.0};
+        bool act = false; int x = 0, y = 0;
+        if (local >= 0 && local < rows_per_thread * W) {
+            x = local % W; y = j + 128 * (local / W);
+            act = y < H;
+        }
+        if (act) {
+            if (x == 0) { left[0] = 0.0; left[1] = 0.0; left[2] = 0.0; }
+            double e[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                double acc = 0.0;
+                if (y > 0) {
+                    if (x > 0) acc += ring[up][(x - 1) & 3][c] * mult * w3;
+                    acc += ring[up][x & 3][c] * mult * w2;
+                    if (x + 1 < W) acc += ring[up][(x + 1) & 3][c] * mult * w1;
+                }
+                if (x > 0) acc += left[c] * mult * w0;
+                e[c] = acc;
+            }
+            const size_t px = (size_t)y * W + x;
+            const uint32_t o = reinterpret_cast<const uint32_t *>(P.orig)[px];
+            const bool opaque = (o >> 24) != 0;
+            double target[3] = {(double)(o & 0xff) + e[0], (double)((o >> 8) & 0xff) + e[1], (double)((o >> 16) & 0xff) + e[2]};
+            uint32_t tq[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                double cl = target[c] < 0.0 ? 0.0 : (target[c] > 255.0 ? 255.0 : target[c]);
+                tq[c] = (uint32_t)round(cl); // Rust f64::round: half away from zero
+            }
+            const uint32_t trgb = tq[0] | (tq[1] << 8) | (tq[2] << 16);
+            const int base = (int)P.tile_pal[(x >> 3) + (y >> 3) * (W >> 3)] * P.sub_size;
+            int best = 0;
+            if (!P.perceptual) {
+                uint32_t bk = 0xffffffffu;
+                for (int i = 0; i < P.sub_size; i++) { uint32_t k = red_mean_key(s_rgb8[base + i], trgb); if (i == 0 || k < bk) { bk = k; best = i; } }
+            } else {
+                Lab tl = linear_to_lab(s_eotf[tq[0]], s_eotf[tq[1]], s_eotf[tq[2]]);
+                float bd = 0.0f;
+                for (int i = 0; i < P.sub_size; i++) {
+                    Lab el; el.l = s_lab[3 * (base + i)]; el.a = s_lab[3 * (base + i) + 1]; el.b = s_lab[3 * (base + i) + 2];
+                    float d = ciede2000(el, tl);
+                    if (i == 0 || d < bd) { bd = d; best = i; }
+                }
+            }
+            const uint8_t m = opaque ? (uint8_t)best : 0;
+            map[px] = m;
+            if (mapT) mapT[(size_t)x * H + y] = m;
+            const uint32_t nc = s_rgb8[base + best];
+            if (opaque) { v[0] = target[0] - (double)(nc & 0xff); v[1] = target[1] - (double)((nc >> 8) & 0xff); v[2] = target[2] - (double)((nc >> 16) & 0xff); }
+            else { v[0] = e[0]; v[1] = e[1]; v[2] = e[2]; } // transparent pixels forward their incoming error (lib.rs:469-474)
+            left[0] = v[0]; left[1] = v[1]; left[2] = v[2];
+        }
+        __syncthreads(); // every read of the ring for step t is done
+        if (act) { ring[j][x & 3][0] = v[0]; ring[j][x & 3][1] = v[1]; ring[j][x & 3][2] = v[2]; }
+        __syncthreads();
+    }
+}
+
+// ---- optimizer step: candidates and commit -------------------------------------------------------
+struct StepResult { double error; int32_t best_k; uint8_t rgb5[3]; uint8_t changed; };
+
+__device__ __forceinline__ unsigned long long dev_mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// method 0: r,g,b sampled in that order from the counter RNG (lib.rs:206-208); 1: 32 values of one
+// channel of the current colour (lib.rs:296-297); 2: the NES table (lib.rs:252-253)
+__global__ void k_gen_candidates(int method, int n, unsigned long long key, const uint8_t *__restrict__ colors, int slot, int channel, uint8_t *__restrict__ cand) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint8_t c[3];
+    if (method == 0) {
+        unsigned long long z = dev_mix64(key + ((unsigned long long)k + 1ull) * 0x9E3779B97F4A7C15ull);
+        c[0] = (uint8_t)(z & 31); c[1] = (uint8_t)((z >> 5) & 31); c[2] = (uint8_t)((z >> 10) & 31);
+    } else if (method == 1) {
+        c[0] = colors[3 * slot]; c[1] = colors[3 * slot + 1]; c[2] = colors[3 * slot + 2];
+        c[channel] = (uint8_t)k;
+    } else {
+        if (k < (int)kNesColorCount) { c[0] = kNesTableDev[k][0]; c[1] = kNesTableDev[k][1]; c[2] = kNesTableDev[k][2]; } else { c[0] = c[1] = c[2] = 0; }
+    }
+    cand[3 * k] = c[0]; cand[3 * k + 1] = c[1]; cand[3 * k + 2] = c[2];
+}
+
+// Keep candidates k with k % count == rank (compacted, in order); errors[] <- +inf everywhere.
+__global__ void k_shard_select(const uint8_t *__restrict__ cand, int n, int rank, int count, uint8_t *__restrict__ sel, double *__restrict__ errors) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    errors[k] = __longlong_as_double(0x7ff0000000000000ll);
+    if (k % count == rank) { int j = k / count; sel[3 * j] = cand[3 * k]; sel[3 * j + 1] = cand[3 * k + 1]; sel[3 * j + 2] = cand[3 * k + 2]; }
+}
+
+// Acceptance rule: ascending k, strict `<` against the running best starting from the incumbent
+// (lib.rs:216-219, 302-305) or from f64::MAX for the NES method (lib.rs:250, 258-261).
+__global__ void k_commit(const double *__restrict__ errors, int n, const uint8_t *__restrict__ cand, uint8_t *__restrict__ colors, int slot, int nes, double *__restrict__ inc_err,
+                         StepResult *__restrict__ last) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double best = nes ? 1.7976931348623157e308 : *inc_err;
+    int best_k = -1;
+    for (int k = 0; k < n; k++) { double e = errors[k]; if (e < best) { best = e; best_k = k; } }
+    uint8_t c[3] = {colors[3 * slot], colors[3 * slot + 1], colors[3 * slot + 2]};
+    uint8_t changed = 0;
+    if (nes && best_k < 0) best_k = 0; // best_index = 0 (lib.rs:249)
+    if (best_k >= 0) {
+        uint8_t nc[3] = {cand[3 * best_k], cand[3 * best_k + 1], cand[3 * best_k + 2]};
+        changed = (nc[0] != c[0] || nc[1] != c[1] || nc[2] != c[2]) ? 1 : 0;
+        c[0] = nc[0]; c[1] = nc[1]; c[2] = nc[2];
+        colors[3 * slot] = c[0]; colors[3 * slot + 1] = c[1]; colors[3 * slot + 2] = c[2];
+        if (best < 1.7976931348623157e308) *inc_err = best; // error() of the committed state (lib.rs:910)
+    }
+    last->error = *inc_err; last->best_k = best_k; last->rgb5[0] = c[0]; last->rgb5[1] = c[1]; last->rgb5[2] = c[2]; last->changed = changed;
+}
+
+// ---- deterministic-math probes for the bit-parity tests -------------------------------------------
+__global__ void k_debug_math(int op, const float *__restrict__ x, const float *__restrict__ y, int n, const float *__restrict__ lab_eotf, float *__restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    switch (op) {
+    case 0: out[i] = d_sinf(x[i]); break;
+    case 1: out[i] = d_cosf(x[i]); break;
+    case 2: out[i] = d_expf_neg(x[i]); break;
+    case 3: out[i] = d_cbrtf(x[i]); break;
+    case 4: out[i] = d_atan2f(y[i], x[i]); break;
+    case 5: { Lab a{x[3 * i], x[3 * i + 1], x[3 * i + 2]}, b{y[3 * i], y[3 * i + 1], y[3 * i + 2]}; out[i] = ciede2000(a, b); break; }
+    default: {
+        Lab l = linear_to_lab(lab_eotf[(int)x[3 * i] & 255], lab_eotf[(int)x[3 * i + 1] & 255], lab_eotf[(int)x[3 * i + 2] & 255]);
+        out[3 * i] = l.l; out[3 * i + 1] = l.a; out[3 * i + 2] = l.b; break;
+    }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k-means (cogset 0.2.0 Kmeans::new restated): Lloyd on points [n][3] f64.
+// Batched over `nprob` independent problems (one per subpalette).  Per iteration:
+//   k_km_assign : thread per point, squared distance to every centre, first minimum wins
+//   k_km_update : one block per problem; thread 0 sums the costs in point order, thread 1+i sums
+//                 cluster i's members in point order (the reference's summation orders, so sums,
+//                 centres and the |delta objective| < 1e-6 test are bit-identical), then the
+//                 centres are scaled by 1/count and the convergence flag is set.
+// ------------------------------------------------------------------------------------------------
+struct KmeansWork {
+    double *pts = nullptr; uint32_t *assign = nullptr; double *cost = nullptr; double *centres = nullptr; double *objective = nullptr;
+    int *state = nullptr; // per problem: 0 running, 1 converged
+    uint32_t *counts = nullptr;
+    size_t cap_pts = 0; int cap_prob = 0, cap_k = 0;
+};
+inline void kmeans_free(KmeansWork &w) {
+    if (w.pts) (void)hipFree(w.pts); if (w.assign) (void)hipFree(w.assign); if (w.cost) (void)hipFree(w.cost); if (w.centres) (void)hipFree(w.centres);
+    if (w.objective) (void)hipFree(w.objective); if (w.state) (void)hipFree(w.state); if (w.counts) (void)hipFree(w.counts);
+    w = KmeansWork{};
+}
+
+struct KmParams {
+    const double *pts; uint32_t *assign; double *cost; double *centres; double *objective; int *state; uint32_t *counts;
+    const int *n; const long long *off; // per problem: point count, offset (in points) into pts/assign/cost
+    int k, first, last;
+};
+__global__ __launch_bounds__(256) void k_km_assign(KmParams P) {
+    const int prob = blockIdx.y;
+    if (P.state[prob]) return;
+    const int n = P.n[prob];
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double s_c[256 * 3];
+    for (int i = threadIdx.x; i < P.k * 3; i += blockDim.x) s_c[i] = P.centres[(size_t)prob * P.k * 3 + i];
+    __syncthreads();
+    if (p >= n) return;
+    const double *pt = P.pts + 3 * (P.off[prob] + p);
+    const double a = pt[0], b = pt[1], c = pt[2];
+    double min_dist = __longlong_as_double(0x7ff0000000000000ll);
+    uint32_t index = 0;
+    for (int i = 0; i < P.k; i++) {
+        double d0 = a - s_c[3 * i], d1 = b - s_c[3 * i + 1], d2 = c - s_c[3 * i + 2];
+        double dist = ((0.0 + d0 * d0) + d1 * d1) + d2 * d2;
+        if (dist < min_dist) { min_dist = dist; index = (uint32_t)i; }
+    }
+    P.cost[P.off[prob] + p] = min_dist;
+    P.assign[P.off[prob] + p] = index;
+}
+__global__ __launch_bounds__(256) void k_km_update(KmParams P) {
+    const int prob = blockIdx.x;
+    if (P.state[prob]) return;
+    const int n = P.n[prob];
+    const int t = threadIdx.x;
+    __shared__ double s_obj;
+    __shared__ int s_stop;
+    const uint32_t *assign = P.assign + P.off[prob];
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0; uint32_t cnt = 0;
+    if (t == 0) {
+        const double *cost = P.cost + P.off[prob];
+        double o = 0.0;
+        for (int p = 0; p < n; p++) o = o + cost[p];
+        s_obj = o;
+        int stop = 0;
+        if (!P.first && fabs(o - P.objective[prob]) < 1e-6) stop = 1; // converged: keep the centres of this assignment
+        if (P.last) stop = 1;                                            // iteration cap (100): no further update_centres
+        s_stop = stop;
+    } else if (t <= P.k) {
+        const int i = t - 1;
+        const double *pts = P.pts + 3 * P.off[prob];
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        for (int p = 0; p < n; p++)
+            if (assign[p] == (uint32_t)i) { s0 += pts[3 * p]; s1 += pts[3 * p + 1]; s2 += pts[3 * p + 2]; cnt++; }
+        const double sc = 1.0 / (double)cnt; // empty cluster -> inf -> NaN centre, as in the reference
+        c0 = s0 * sc; c1 = s1 * sc; c2 = s2 * sc;
+    }
+    __syncthreads();
+    if (t == 0) { P.objective[prob] = s_obj; if (s_stop) P.state[prob] = 1; }
+    else if (t <= P.k && !s_stop) {
+        double *c = P.centres + ((size_t)prob * P.k + (t - 1)) * 3;
+        c[0] = c0; c[1] = c1; c[2] = c2;
+        P.counts[(size_t)prob * P.k + (t - 1)] = cnt;
+    }
+}
+
+// per-tile f32 sums in the reference's order (tile pixels x outer, y inner; lib.rs:91-116)
+__global__ void k_tile_sums(const uint8_t *__restrict__ orig, const float *__restrict__ labpx, int W, int H, int perceptual, float *__restrict__ sums /*[tiles][3]*/, int *__restrict__ counts) {
+    int tile = blockIdx.x * blockDim.x + threadIdx.x;
+    int wt = W / 8, ht = H / 8;
+    if (tile >= wt * ht) return;
+    int tx = tile % wt, ty = tile / wt;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f; int cnt = 0;
+    for (int x = 0; x < 8; x++)
+        for (int y = 0; y < 8; y++) {
+            size_t px = (size_t)(ty * 8 + y) * W + tx * 8 + x;
+            uint32_t o = reinterpret_cast<const uint32_t *>(orig)[px];
+            if ((o >> 24) != 0) {
+                if (perceptual) { s0 += labpx[3 * px]; s1 += labpx[3 * px + 1]; s2 += labpx[3 * px + 2]; }
+                else { s0 += (float)(o & 0xff); s1 += (float)((o >> 8) & 0xff); s2 += (float)((o >> 16) & 0xff); }
+                cnt++;
+            }
+        }
+    sums[3 * tile] = s0; sums[3 * tile + 1] = s1; sums[3 * tile + 2] = s2; counts[tile] = cnt;
+}
+// gather k-means points from a pixel index list (RGB as f64, or Lab f32 widened to f64; lib.rs:344-358)
+__global__ void k_gather_points(const uint8_t *__restrict__ orig, const float *__restrict__ labpx, const uint32_t *__restrict__ index, long long n, int perceptual, double *__restrict__ pts) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t px = index[i];
+    if (perceptual) { pts[3 * i] = (double)labpx[3 * (size_t)px]; pts[3 * i + 1] = (double)labpx[3 * (size_t)px + 1]; pts[3 * i + 2] = (double)labpx[3 * (size_t)px + 2]; }
+    else { uint32_t o = reinterpret_cast<const uint32_t *>(orig)[px]; pts[3 * i] = (double)(o & 0xff); pts[3 * i + 1] = (double)((o >> 8) & 0xff); pts[3 * i + 2] = (double)((o >> 16) & 0xff); }
+}
+
+} // namespace snes
