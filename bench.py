@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py — candidate palettes scored per second on MI355X (BASELINE.json's metric).
+
+One *step* = one optimizer call on one palette slot: generate the step's candidates on the device,
+score each (replace the entry -> full-image remap -> 100 - SSIMULACRA2, lib.rs:205-220), pick the
+best by the reference's rule and commit it (lib.rs:236-237).  The slot sequence is the reference's
+scheduler (lib.rs:881-933).  Inputs (image, tile map, palette, source-side pyramid) are resident in
+HBM before the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W [--batch B] [--config rgb|perceptual|dither]
+
+N > 1 is launched by the driver as one process per GPU (torch.distributed.run); ranks shard the
+candidates of every step and exchange ONE RCCL min-all-reduce per step.  `--scaling weak` (default)
+keeps B candidates per GPU per step (N*B per step in total); `--scaling strong` shards a fixed B.
+Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_CANDIDATE = 263408  # 262,144 source RGBA8 + 1,024 tile map + 240 palette
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+
+
+def cpu_baseline(img, sub_count, sub_size, flags, tile_palettes, palette, budget_s=12.0):
+    """Time the CPU oracle (the restated reference, source side recomputed per candidate like
+    lib.rs:506-525) on this host's cores, on a bounded sample of the same workload."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle_py as O
+
+    def make():
+        o = O.OracleImage(img, sub_count, sub_size, dither=bool(flags & 1), perceptual=bool(flags & 2),
+                          cache_source=False)
+        o.tile_palettes = tile_palettes
+        o.palette = palette
+        o.optimize()
+        return o
+
+    one = make()
+    cand = O.random_candidates(1, 123456, 4)
+    t0 = time.perf_counter()
+    one.score_candidates(0, 0, cand)
+    per = (time.perf_counter() - t0) / 4
+    single = 1.0 / per
+    cores = min(os.cpu_count() or 1, 16)
+    per_thread = max(2, int(budget_s / per))
+    workers = [one] + [make() for _ in range(cores - 1)]
+    lists = [O.random_candidates(1, 1000 + i, per_thread) for i in range(cores)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(lambda a: a[0].score_candidates(0, 0, a[1]), zip(workers, lists)))
+    dt = time.perf_counter() - t0
+    return {"value": cores * per_thread / dt, "unit": "candidates/s", "cores": cores, "kind": "port",
+            "single_thread": single,
+            "sample": "%d candidates of slot (0,0) per thread on %d threads, full remap + full SSIMULACRA2 "
+                      "with the source side recomputed per candidate (as lib.rs:506-525)" % (per_thread, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="candidates per step per GPU (weak) or in total (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--config", choices=["rgb", "perceptual", "dither"], default="rgb")
+    ap.add_argument("--chunk", type=int, default=0, help="candidates per launch group (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import snesimage_amd as S
+    from snesimage_amd.distributed import HipShardScorer, sharded_step
+    from snesimage_amd.synth import synth_image
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    sub_count, sub_size = 8, 15
+    flags = {"rgb": 0, "perceptual": S.PERCEPTUAL, "dither": S.DITHER}[args.config]
+    img = synth_image()
+    image = S.OptimizedImage(img, sub_count, sub_size, dither=bool(flags & S.DITHER), perceptual=bool(flags & S.PERCEPTUAL),
+                             device=local_rank)
+    if args.chunk:
+        image.set_chunk(args.chunk)
+    # setup (untimed): the reference's TileAssignment and Clustering phases
+    image.initialize_tiles()
+    image.recalculate_palettes()
+    tile_palettes, palette = image.tile_palettes, image.palette
+    scorer = HipShardScorer(image, device)
+
+    n_total = args.batch * world if args.scaling == "weak" else args.batch
+    slots = S.schedule(sub_count, sub_size, args.warmup + args.steps)
+    seed = 1
+
+    def run(lo, hi):
+        for i in range(lo, hi):
+            method, p, idx, ch, _ = slots[i]
+            # the benchmark scores n_total random candidates on every slot (method 0); the channel sweeps of
+            # lib.rs:286-328 are exercised by the tests
+            sharded_step(scorer, S.METHOD_RANDOM, p, idx, ch, seed, i, n_total)
+
+    run(0, args.warmup)
+    torch.cuda.synchronize()
+    image.timing_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.warmup, args.warmup + args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    tim = image.timing_read()
+    image.timing_enable(False)
+    err, best, _ = image.last_step()
+
+    if rank == 0:
+        total = n_total * args.steps
+        value = total / dt
+        # dominant kernel of the launch group
+        dom = "k_vpass<scale0>" if tim["vpass0_ms"] >= tim["hpass0_ms"] else "k_hpass<scale0>"
+        dom_ms = max(tim["vpass0_ms"], tim["hpass0_ms"]) / max(1, tim["launches"])
+        per_launch = tim["candidates"] / max(1, tim["launches"])
+        achieved = ALGO_BYTES_PER_CANDIDATE * per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        out = {
+            "metric": "candidate palettes scored/sec", "value": value, "unit": "candidates/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "256x256 synthetic RGBA8 (seed 0x5EED0000), 8 subpalettes x 15, %s, %d candidates/step%s, "
+                                   "remap + SSIMULACRA2 per candidate" % (
+                                       {"rgb": "RGB redmean distance, no dither", "perceptual": "CIEDE2000 (--perceptual-palettes), no dither",
+                                        "dither": "RGB redmean + Floyd-Steinberg dither"}[args.config], n_total,
+                                       " (%d per GPU)" % args.batch if world > 1 and args.scaling == "weak" else ""),
+                       "batch": args.batch, "candidates_per_step": n_total, "config": args.config, "final_error": err},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_candidate": ALGO_BYTES_PER_CANDIDATE, "candidates_per_launch": per_launch,
+                         "avg_launch_ms": dom_ms, "group_ms": tim["group_ms"] / max(1, tim["launches"]),
+                         "pipeline_achieved": value / world * ALGO_BYTES_PER_CANDIDATE / 1e9,
+                         "pipeline_frac": value / world * ALGO_BYTES_PER_CANDIDATE / 1e9 / HBM_PEAK_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(img, sub_count, sub_size, flags, tile_palettes, palette)
+        print(json.dumps(out), flush=True)
+    image.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

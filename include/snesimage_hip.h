@@ -119,11 +119,13 @@ void snesimage_schedule_next(uint32_t sub_count, uint32_t sub_size, int32_t nes,
  * 6 sRGB8->Lab (x holds r,g,b as floats, out 3 per item). Host pointers. */
 int32_t snesimage_debug_math(int32_t device, int32_t op, const float *x, const float *y, uint32_t n,
                              float *out);
-/* Average duration in milliseconds of the scoring kernels recorded by the library's own HIP
- * events since the last reset (bench.py's roofline leg). which: 0 = all scoring kernels of a
- * call.  Returns negative if timing was not enabled. */
+/* Launch timing by the library's own HIP events on the context's stream (bench.py's roofline leg).
+ * While enabled, every scoring launch group records events; timing_read() returns the summed
+ * milliseconds ms3[0] = whole launch group (all kernels that score one chunk of candidates),
+ * ms3[1] = k_hpass at scale 0, ms3[2] = k_vpass at scale 0 (the dominant kernel), the number of
+ * launch groups and the candidates they scored since timing was enabled. */
 int32_t snesimage_timing_enable(snesimage_ctx *ctx, int32_t on);
-int32_t snesimage_timing_read(snesimage_ctx *ctx, double *total_ms, uint64_t *launches,
+int32_t snesimage_timing_read(snesimage_ctx *ctx, double *ms3, uint64_t *launches,
                               uint64_t *candidates);
 
 const char *snesimage_last_error(void);

@@ -98,9 +98,10 @@ class OptimizedImage:
         self._chk(self._L.snesimage_timing_enable(self._c, int(on)))
 
     def timing_read(self):
-        ms, n, k = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
-        self._chk(self._L.snesimage_timing_read(self._c, C.byref(ms), C.byref(n), C.byref(k)))
-        return ms.value, n.value, k.value
+        ms = (C.c_double * 3)()
+        n, k = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._L.snesimage_timing_read(self._c, ms, C.byref(n), C.byref(k)))
+        return {"group_ms": ms[0], "hpass0_ms": ms[1], "vpass0_ms": ms[2], "launches": n.value, "candidates": k.value}
 
     # -- the reference's methods ------------------------------------------------------------------
     def initialize_tiles(self):  # lib.rs:79

@@ -126,9 +126,10 @@ struct snesimage_ctx {
     uint32_t pend_n = 0, pend_sp = 0, pend_si = 0, pend_method = 0; bool pend = false;
 
     // timing
-    bool timing = false; hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double t_total_ms = 0.0; uint64_t t_launches = 0, t_cands = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> t_pending; std::vector<uint32_t> t_pending_n;
+    bool timing = false;
+    double t_ms[3] = {0.0, 0.0, 0.0}; uint64_t t_launches = 0, t_cands = 0; // [0] whole launch group, [1] k_hpass scale 0, [2] k_vpass scale 0
+    struct TimingRec { hipEvent_t ev[6]; uint32_t n; };
+    std::vector<TimingRec> t_pending;
 };
 
 namespace {
@@ -213,6 +214,11 @@ int32_t run_prep(snesimage_ctx *c, int mode, int sp, int si) {
     return SNES_OK;
 }
 
+// Without dither the pack carries, per pixel, the best non-slot entry and the key the candidate must beat
+// (mode 2).  With dither every candidate gets its own map from k_dither; the pack is then only consulted for
+// the transparent-pixel marker, which any mode provides (mode 1 is the cheapest).
+int32_t prep_for_slot(snesimage_ctx *c, int sp, int si) { return c->dither ? run_prep(c, 1, -1, -1) : run_prep(c, 2, sp, si); }
+
 // Score nc candidates (device rgb5 list) given a prepared pack; errors -> d_errors[err_offset + k*err_stride].
 // slot_ci: colour index of the slot being replaced (dither path), or -1.
 int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double *d_errors, int err_stride, int err_offset, int sp, int si, uint8_t *d_maps_out) {
@@ -220,8 +226,8 @@ int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double
     const int npairs = (int)nc * 3;
     const bool use_maps = c->dither;
     const uint32_t slot_ci = (sp >= 0) ? (uint32_t)(sp * (int)c->sub_size + si) : 0xffffffffu;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->timing) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, c->stream)); }
+    snesimage_ctx::TimingRec tr{}; tr.n = nc;
+    if (c->timing) { for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&tr.ev[i])); HIPCHK(hipEventRecord(tr.ev[0], c->stream)); }
     hipLaunchKernelGGL(k_candidate_tables, dim3((nc + 63) / 64), dim3(64), 0, c->stream, d_rgb5, (int)nc, c->d_eotf, c->d_cand_tab);
     hipLaunchKernelGGL(k_candidate_slot, dim3((nc + 63) / 64), dim3(64), 0, c->stream, c->d_cand_tab, (int)nc, slot_ci);
     if (c->perceptual) hipLaunchKernelGGL(k_candidate_lab, dim3((nc + 63) / 64), dim3(64), 0, c->stream, c->d_cand_tab, (int)nc, c->d_lab_eotf, c->d_cand_lab);
@@ -249,8 +255,10 @@ int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double
         int ppw = 256 / G.sh[s];
         dim3 grid((npairs + ppw - 1) / ppw);
         if (s == 0) {
+            if (c->timing) HIPCHK(hipEventRecord(tr.ev[1], c->stream));
             if (c->perceptual && !use_maps) hipLaunchKernelGGL((k_hpass<true, true>), grid, dim3(256), 0, c->stream, Hp);
             else hipLaunchKernelGGL((k_hpass<true, false>), grid, dim3(256), 0, c->stream, Hp);
+            if (c->timing) HIPCHK(hipEventRecord(tr.ev[2], c->stream));
         } else hipLaunchKernelGGL((k_hpass<false, false>), grid, dim3(256), 0, c->stream, Hp);
     }
     for (int s = 0; s < G.nscales; s++) {
@@ -261,13 +269,15 @@ int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double
         int ppv = 256 / G.sw[s];
         dim3 grid((npairs + ppv - 1) / ppv);
         if (s == 0) {
+            if (c->timing) HIPCHK(hipEventRecord(tr.ev[3], c->stream));
             if (c->perceptual && !use_maps) hipLaunchKernelGGL((k_vpass<true, false, true>), grid, dim3(256), 0, c->stream, Vp);
             else hipLaunchKernelGGL((k_vpass<true, false, false>), grid, dim3(256), 0, c->stream, Vp);
+            if (c->timing) HIPCHK(hipEventRecord(tr.ev[4], c->stream));
         } else hipLaunchKernelGGL((k_vpass<false, false, false>), grid, dim3(256), 0, c->stream, Vp);
     }
     hipLaunchKernelGGL(k_final_score, dim3((nc + 63) / 64), dim3(64), 0, c->stream, c->d_part, (int)nc, G, d_errors, err_stride, err_offset);
     HIPCHK(hipGetLastError());
-    if (c->timing) { HIPCHK(hipEventRecord(e1, c->stream)); c->t_pending.emplace_back(e0, e1); c->t_pending_n.push_back(nc); }
+    if (c->timing) { HIPCHK(hipEventRecord(tr.ev[5], c->stream)); c->t_pending.push_back(tr); }
     return SNES_OK;
 }
 
@@ -337,14 +347,16 @@ int32_t check_slot(snesimage_ctx *c, uint32_t palette, uint32_t index) {
 int32_t set_device(snesimage_ctx *c) { HIPCHK(hipSetDevice(c->device)); return SNES_OK; }
 
 int32_t drain_timing(snesimage_ctx *c) {
-    for (size_t i = 0; i < c->t_pending.size(); i++) {
+    for (auto &r : c->t_pending) {
         float ms = 0.0f;
-        HIPCHK(hipEventSynchronize(c->t_pending[i].second));
-        HIPCHK(hipEventElapsedTime(&ms, c->t_pending[i].first, c->t_pending[i].second));
-        c->t_total_ms += ms; c->t_launches += 1; c->t_cands += c->t_pending_n[i];
-        (void)hipEventDestroy(c->t_pending[i].first); (void)hipEventDestroy(c->t_pending[i].second);
+        HIPCHK(hipEventSynchronize(r.ev[5]));
+        HIPCHK(hipEventElapsedTime(&ms, r.ev[0], r.ev[5])); c->t_ms[0] += ms;
+        HIPCHK(hipEventElapsedTime(&ms, r.ev[1], r.ev[2])); c->t_ms[1] += ms;
+        HIPCHK(hipEventElapsedTime(&ms, r.ev[3], r.ev[4])); c->t_ms[2] += ms;
+        c->t_launches += 1; c->t_cands += r.n;
+        for (int i = 0; i < 6; i++) (void)hipEventDestroy(r.ev[i]);
     }
-    c->t_pending.clear(); c->t_pending_n.clear();
+    c->t_pending.clear();
     return SNES_OK;
 }
 
@@ -396,7 +408,12 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     if (const char *e = getenv("SNES_CHUNK")) { int v = atoi(e); if (v > 0) c->chunk = (uint32_t)v; }
     Geom &G = c->G;
     G.W = (int)w; G.H = (int)h; G.nscales = 0;
-    for (int s = 0; s < kMaxScales; s++) { if (((int)w >> s) < 8 || ((int)h >> s) < 8) break; G.sw[s] = (int)w >> s; G.sh[s] = (int)h >> s; G.nscales = s + 1; }
+    // ssimulacra2's scale loop tests the size BEFORE downscaling (`if width < 8 || height < 8 { break }` then
+    // `downscale_by_2`), so the last scale computed may be as small as 4 rows: 256x8 -> scales 256x8 and 128x4.
+    for (int s = 0; s < kMaxScales; s++) {
+        if (s > 0 && (G.sw[s - 1] < 8 || G.sh[s - 1] < 8)) break;
+        G.sw[s] = (int)w >> s; G.sh[s] = (int)h >> s; G.nscales = s + 1;
+    }
     long long off = 0, soff = 0;
     for (int s = 0; s < G.nscales; s++) {
         long long N = (long long)G.sw[s] * G.sh[s];
@@ -510,8 +527,7 @@ int32_t snesimage_score_candidates_device(snesimage_ctx *c, uint32_t palette, ui
     if (!d_rgb5 || !d_errors) return fail(SNES_ERR_ARG, "null pointer");
     if (n == 0) return SNES_OK;
     CHECK(set_device(c));
-    if (!c->dither) CHECK(run_prep(c, 2, (int)palette, (int)index));
-    else CHECK(ensure_tables(c));
+    CHECK(prep_for_slot(c, (int)palette, (int)index));
     CHECK(score_list(c, d_rgb5, n, d_errors, (int)palette, (int)index, d_maps_out));
     return SNES_OK;
 }
@@ -537,7 +553,7 @@ int32_t snesimage_step_async(snesimage_ctx *c, uint32_t method, uint32_t palette
     CHECK(ensure_cand_capacity(c, n));
     if (method != SNES_METHOD_NES) CHECK(ensure_incumbent(c)); // lib.rs:199, 294 (nes: f64::MAX, lib.rs:250)
     CHECK(gen_candidates(c, method, palette, index, channel, seed, step_id, n));
-    if (!c->dither) CHECK(run_prep(c, 2, (int)palette, (int)index));
+    CHECK(prep_for_slot(c, (int)palette, (int)index));
     CHECK(score_list(c, c->d_cand, n, c->d_errs, (int)palette, (int)index, nullptr));
     CHECK(commit(c, c->d_errs, n, method, palette, index));
     return SNES_OK;
@@ -574,7 +590,7 @@ int32_t snesimage_step_begin(snesimage_ctx *c, uint32_t method, uint32_t palette
     hipLaunchKernelGGL(k_shard_select, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->d_cand, (int)n, (int)shard_rank, (int)shard_count, c->d_cand_sel, d_errors);
     HIPCHK(hipGetLastError());
     if (n_own) {
-        if (!c->dither) CHECK(run_prep(c, 2, (int)palette, (int)index));
+        CHECK(prep_for_slot(c, (int)palette, (int)index));
         CHECK(alloc_workspace(c, c->chunk));
         CHECK(ensure_tables(c));
         CHECK(ensure_source(c));
@@ -743,14 +759,14 @@ int32_t snesimage_timing_enable(snesimage_ctx *c, int32_t on) {
     CHECK(set_device(c));
     HIPCHK(hipStreamSynchronize(c->stream));
     CHECK(drain_timing(c));
-    c->timing = on != 0; c->t_total_ms = 0.0; c->t_launches = 0; c->t_cands = 0;
+    c->timing = on != 0; c->t_ms[0] = c->t_ms[1] = c->t_ms[2] = 0.0; c->t_launches = 0; c->t_cands = 0;
     return SNES_OK;
 }
-int32_t snesimage_timing_read(snesimage_ctx *c, double *total_ms, uint64_t *launches, uint64_t *candidates) {
+int32_t snesimage_timing_read(snesimage_ctx *c, double *ms3, uint64_t *launches, uint64_t *candidates) {
     if (!c) return fail(SNES_ERR_ARG, "null context");
     CHECK(set_device(c));
     CHECK(drain_timing(c));
-    if (total_ms) *total_ms = c->t_total_ms;
+    if (ms3) { ms3[0] = c->t_ms[0]; ms3[1] = c->t_ms[1]; ms3[2] = c->t_ms[2]; }
     if (launches) *launches = c->t_launches;
     if (candidates) *candidates = c->t_cands;
     return SNES_OK;

@@ -1,0 +1,156 @@
+// snesimage_amd/csrc/cli.cpp — headless driver over the C ABI, keeping the reference's command line
+// (src/config.rs:3-31: source_filename target_filename [-c N] [-s N] [-d] [--perceptual-palettes]
+// [--nes]) and its JSON output (src/lib.rs:579-625, 1002).  The reference drives the optimizer from
+// an SDL2 window (src/lib.rs:855-1038, out of scope); here the three phases advance on their own:
+// TileAssignment (initialize_tiles) -> Clustering (recalculate_palettes) -> Optimization for
+// --calls optimizer calls in the reference's slot order (src/lib.rs:881-933) -> write the JSON.
+// Extra flags exist only because the reference is interactive and unseeded: --seed, --calls,
+// --candidates, --device, --tile-palettes FILE (1024 bytes, replaces the mouse clicks of
+// src/lib.rs:1005-1017).  The source image is a raw RGBA8 file of 256*H*4 bytes, or `synth:SEED`.
+// The host language the north star asks for is Rust; no Rust toolchain exists in this image, so the
+// driver is C++ over the same extern "C" surface a Rust crate would bind.
+#include "../../include/snesimage_hip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include <vector>
+
+namespace {
+
+void log_info(const std::string &msg) { // src/util.rs:9-22: [time][level][target] message
+    char ts[64];
+    time_t now = time(nullptr);
+    strftime(ts, sizeof ts, "%Y-%m-%d %H:%M:%S", localtime(&now));
+    printf("[%s][INFO][snesimage] %s\n", ts, msg.c_str());
+    fflush(stdout);
+}
+[[noreturn]] void die(const std::string &msg) { // src/main.rs:16-19
+    char ts[64];
+    time_t now = time(nullptr);
+    strftime(ts, sizeof ts, "%Y-%m-%d %H:%M:%S", localtime(&now));
+    printf("[%s][ERROR][snesimage] Error running application: %s\n", ts, msg.c_str());
+    exit(1);
+}
+std::string fmt_f64(double v) { // Rust's `{}` for f64: shortest representation that round-trips
+    char buf[64];
+    for (int prec = 1; prec <= 17; prec++) {
+        snprintf(buf, sizeof buf, "%.*g", prec, v);
+        if (strtod(buf, nullptr) == v) break;
+    }
+    return buf;
+}
+void usage() {
+    fprintf(stderr,
+            "Usage: snesimage_cli [OPTIONS] <SOURCE_FILENAME> <TARGET_FILENAME>\n\n"
+            "Arguments:\n  <SOURCE_FILENAME>  raw RGBA8 file (256 x H x 4 bytes) or synth:SEED\n  <TARGET_FILENAME>  JSON output\n\n"
+            "Options:\n  -c, --subpalette-count <N>  [default: 1]\n  -s, --subpalette-size <N>   [default: 7]\n"
+            "  -d, --dither\n      --perceptual-palettes\n      --nes\n"
+            "      --calls <N>          optimizer calls to run [default: 0]\n      --candidates <N>     random candidates per call [default: 64]\n"
+            "      --seed <N>           candidate RNG seed [default: 1]\n      --device <N>         HIP device [default: 0]\n"
+            "      --tile-palettes <F>  1024-byte tile->subpalette override\n  -h, --help\n  -V, --version\n");
+}
+void synth(uint64_t seed, uint32_t w, uint32_t h, std::vector<uint8_t> &out) {
+    out.resize((size_t)w * h * 4);
+    uint64_t s = seed;
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+            uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z ^= z >> 31;
+            uint8_t *o = &out[4 * ((size_t)y * w + x)];
+            o[0] = (uint8_t)(x + (z & 63)); o[1] = (uint8_t)(y + ((z >> 8) & 63)); o[2] = (uint8_t)((x + y) / 2 + ((z >> 16) & 63)); o[3] = 255;
+        }
+}
+
+} // namespace
+
+int main(int argc, char **argv) {
+    std::vector<std::string> pos;
+    uint32_t count = 1, size = 7, flags = 0, calls = 0, ncand = 64; // src/config.rs:13-18 defaults
+    uint64_t seed = 1;
+    int device = 0;
+    std::string tile_file;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto need = [&](const char *name) -> const char * { if (i + 1 >= argc) { fprintf(stderr, "error: a value is required for '%s'\n", name); exit(2); } return argv[++i]; };
+        if (a == "-c" || a == "--subpalette-count") count = (uint32_t)strtoul(need("--subpalette-count"), nullptr, 10);
+        else if (a == "-s" || a == "--subpalette-size") size = (uint32_t)strtoul(need("--subpalette-size"), nullptr, 10);
+        else if (a == "-d" || a == "--dither") flags |= SNES_DITHER;
+        else if (a == "--perceptual-palettes") flags |= SNES_PERCEPTUAL;
+        else if (a == "--nes") flags |= SNES_NES;
+        else if (a == "--calls") calls = (uint32_t)strtoul(need("--calls"), nullptr, 10);
+        else if (a == "--candidates") ncand = (uint32_t)strtoul(need("--candidates"), nullptr, 10);
+        else if (a == "--seed") seed = strtoull(need("--seed"), nullptr, 0);
+        else if (a == "--device") device = atoi(need("--device"));
+        else if (a == "--tile-palettes") tile_file = need("--tile-palettes");
+        else if (a == "-h" || a == "--help") { usage(); return 0; }
+        else if (a == "-V" || a == "--version") { printf("snesimage 0.1.1 (%s)\n", snesimage_version()); return 0; }
+        else if (!a.empty() && a[0] == '-' && a != "-") { fprintf(stderr, "error: unexpected argument '%s' found\n", a.c_str()); usage(); return 2; }
+        else pos.push_back(a);
+    }
+    if (pos.size() != 2) { fprintf(stderr, "error: the following required arguments were not provided: <SOURCE_FILENAME> <TARGET_FILENAME>\n"); usage(); return 2; }
+    const std::string source = pos[0], target = pos[1];
+
+    log_info("Using source image: " + source); // src/lib.rs:834
+    std::vector<uint8_t> rgba;
+    uint32_t w = 256, h = 256;
+    if (source.rfind("synth:", 0) == 0) synth(strtoull(source.c_str() + 6, nullptr, 0), w, h, rgba);
+    else {
+        FILE *f = fopen(source.c_str(), "rb");
+        if (!f) die("No such file or directory: " + source);
+        fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+        if (n <= 0 || n % (256 * 4) != 0) { fclose(f); die("Image size must be 256x256"); } // src/lib.rs:838-840
+        h = (uint32_t)(n / (256 * 4));
+        rgba.resize((size_t)n);
+        if (fread(rgba.data(), 1, (size_t)n, f) != (size_t)n) { fclose(f); die("short read on " + source); }
+        fclose(f);
+    }
+    snesimage_ctx *ctx = nullptr;
+    if (snesimage_create(rgba.data(), w, h, count, size, flags, device, &ctx) != 0) die(snesimage_last_error());
+    if (snesimage_initialize_tiles(ctx) != 0) die(std::string("Unable to initialize tiles: ") + snesimage_last_error()); // src/lib.rs:851-853
+    log_info("Finished assigning initial tiles");
+    if (!tile_file.empty()) {
+        std::vector<uint8_t> tp(1024);
+        FILE *f = fopen(tile_file.c_str(), "rb");
+        if (!f || fread(tp.data(), 1, 1024, f) != 1024) die("cannot read 1024 bytes from " + tile_file);
+        fclose(f);
+        if (snesimage_set_tile_palettes(ctx, tp.data()) != 0) die(snesimage_last_error());
+    }
+    log_info("Generating initial palettes"); // src/lib.rs:985-989
+    if (snesimage_recalculate_palettes(ctx) != 0) die(std::string("Unable to recalculate palettes: ") + snesimage_last_error());
+    log_info("Beginning optimization"); // src/lib.rs:992
+    uint32_t palette = 0, index = 0, channel = 0, step = 0;
+    double last_error = 1.7976931348623157e308;
+    std::vector<uint8_t> before(3 * (size_t)count * size), after(before.size());
+    for (uint32_t call = 0; call < calls; call++) {
+        uint32_t p = palette, ix = index, ch = channel, method = 0;
+        snesimage_schedule_next(count, size, (flags & SNES_NES) ? 1 : 0, &palette, &index, &channel, &step, &method);
+        snesimage_get_palette_rgb5(ctx, before.data());
+        double error = 0.0; uint8_t best[3];
+        if (snesimage_step(ctx, method, p, ix, ch, seed, call, method == SNES_METHOD_RANDOM ? ncand : 0, &error, best) != 0)
+            die(std::string("Unable to optimize palette: ") + snesimage_last_error());
+        const uint8_t *b = &before[3 * ((size_t)p * size + ix)];
+        if (b[0] != best[0] || b[1] != best[1] || b[2] != best[2]) { // src/lib.rs:222-234
+            char m[160];
+            snprintf(m, sizeof m, "Setting color (%u, %u) from (%u, %u, %u) to (%u, %u, %u)", p, ix, b[0], b[1], b[2], best[0], best[1], best[2]);
+            log_info(m);
+        }
+        if (std::abs(error - last_error) > 2.220446049250313e-16) { log_info("Current Error: " + fmt_f64(error)); last_error = error; } // src/lib.rs:912-915
+    }
+    log_info("Writing output to " + target); // src/lib.rs:1000-1002
+    int64_t need = snesimage_as_json(ctx, nullptr, 0);
+    if (need < 0) die(snesimage_last_error());
+    std::vector<char> json((size_t)need);
+    snesimage_as_json(ctx, json.data(), need);
+    FILE *f = fopen(target.c_str(), "wb");
+    if (!f) die("cannot create " + target);
+    fwrite(json.data(), 1, (size_t)need - 1, f);
+    fclose(f);
+    snesimage_destroy(ctx);
+    return 0;
+}

@@ -1,0 +1,361 @@
+"""Parity of the HIP path against the CPU oracle, through the C ABI, on a real MI355X.
+
+Bars (north_star): palette/tile indices bit-exact; SSIMULACRA2 error within 1e-5 relative.  The
+kernels keep the oracle's binary32 operation order, so the tests hold the error to 1e-11 relative
+(only the order of the binary64 pooling sums differs).
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_ERR = 1e-11  # far inside the 1e-5 the north star allows
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
+
+
+@pytest.fixture(scope="module")
+def S():
+    import snesimage_amd
+    return snesimage_amd
+
+
+def pair(S, O, img, count, size, **kw):
+    g = S.OptimizedImage(img, count, size, **kw)
+    o = O.OracleImage(img, count, size, **kw)
+    return g, o
+
+
+def sync_state(g, o):
+    g.tile_palettes = o.tile_palettes
+    g.palette = o.palette
+    g.palette_map = o.palette_map
+
+
+# ---- deterministic math: device bits == oracle bits -------------------------------------------------
+def test_device_math_bit_exact(S, O):
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-30, 30, 20000).astype(np.float32)
+    assert np.array_equal(S.debug_math(0, x), O.det_math(0, x))
+    assert np.array_equal(S.debug_math(1, x), O.det_math(1, x))
+    xe = np.concatenate([rng.uniform(-130, 0, 20000), [-0.0, -1e-30, -800.0]]).astype(np.float32)
+    assert np.array_equal(S.debug_math(2, xe), O.det_math(2, xe))
+    xc = np.concatenate([rng.uniform(0, 4, 20000), [0.0, 1e-20, 1.0, 8.0]]).astype(np.float32)
+    assert np.array_equal(S.debug_math(3, xc), O.det_math(3, xc))
+    ya, xa = rng.uniform(-5, 5, 20000).astype(np.float32), rng.uniform(-5, 5, 20000).astype(np.float32)
+    ya[:4], xa[:4] = [0.0, 0.0, 1.0, -1.0], [1.0, -1.0, 0.0, 0.0]
+    assert np.array_equal(S.debug_math(4, xa, ya), O.det_math(4, xa, ya))
+
+
+def test_device_lab_and_ciede_bit_exact(S, O):
+    rng = np.random.default_rng(12)
+    rgb = rng.integers(0, 256, size=(4000, 3)).astype(np.uint8)
+    lab_dev = S.debug_math(6, rgb.astype(np.float32)).reshape(-1, 3)
+    lab_ref = np.stack([O.srgb8_to_lab(c) for c in rgb])
+    assert np.array_equal(lab_dev, lab_ref)
+    a, b = lab_ref[:2000], lab_ref[2000:]
+    d_dev = S.debug_math(5, a, b)
+    d_ref = np.array([O.ciede2000(p, q) for p, q in zip(a, b)], np.float32)
+    assert np.array_equal(d_dev, d_ref)
+    grey = np.array([[50.0, 0.0, 0.0]], np.float32)  # zero-chroma branch
+    assert np.array_equal(S.debug_math(5, grey, a[:1]), np.array([O.ciede2000(grey[0], a[0])], np.float32))
+
+
+# ---- remap (optimize) -----------------------------------------------------------------------------
+@pytest.mark.parametrize("count,size,flags", [(1, 15, {}), (8, 15, {}), (4, 7, {}), (8, 15, {"perceptual": True}),
+                                              (8, 15, {"dither": True}), (2, 3, {"dither": True, "perceptual": True})])
+def test_optimize_map_bit_exact(S, O, img256, img256_alpha, count, size, flags):
+    for img in (img256, img256_alpha):
+        g, o = pair(S, O, img, count, size, **flags)
+        o.initialize_tiles()
+        o.recalculate_palettes()
+        sync_state(g, o)
+        g.optimize()
+        assert np.array_equal(g.palette_map, o.palette_map)
+        assert rel(g.error(), o.error()) < REL_ERR
+        g.optimize()  # idempotent
+        assert np.array_equal(g.palette_map, o.palette_map)
+        g.close()
+
+
+# ---- k-means initialisers ---------------------------------------------------------------------------
+@pytest.mark.parametrize("count,size,flags", [(1, 15, {}), (8, 15, {}), (4, 7, {"perceptual": True}), (2, 3, {"nes": True}),
+                                              (2, 3, {"nes": True, "perceptual": True}), (8, 15, {"dither": True})])
+def test_kmeans_initialisers_bit_exact(S, O, img256, img256_alpha, count, size, flags):
+    for img in (img256, img256_alpha):
+        g, o = pair(S, O, img, count, size, **flags)
+        g.initialize_tiles()
+        o.initialize_tiles()
+        assert np.array_equal(g.tile_palettes, o.tile_palettes)
+        assert np.array_equal(g.palette, o.palette)
+        assert np.array_equal(g.palette_map, o.palette_map)
+        g.recalculate_palettes()
+        o.recalculate_palettes()
+        assert np.array_equal(g.palette, o.palette)
+        assert np.array_equal(g.palette_map, o.palette_map)
+        assert g.as_json() == o.as_json()
+        assert np.array_equal(g.as_rgba(), o.as_rgba())
+        assert np.array_equal(g.palette_u16, o.palette_u16)
+        g.close()
+
+
+def test_kmeans_precondition_is_an_error(S, O):
+    img = np.zeros((8, 256, 4), np.uint8)  # fully transparent: no points (the reference panics in cogset)
+    g = S.OptimizedImage(img, 1, 3)
+    with pytest.raises(S.SnesImageError) as e:
+        g.initialize_tiles()
+    assert e.value.code == -4
+    o = O.OracleImage(img, 1, 3)
+    with pytest.raises(RuntimeError):
+        o.initialize_tiles()
+
+
+# ---- candidate scoring ------------------------------------------------------------------------------
+@pytest.mark.parametrize("flags,slot,n", [({}, (2, 3), 24), ({}, (7, 14), 9), ({"perceptual": True}, (0, 0), 6),
+                                          ({"dither": True}, (5, 1), 6), ({"dither": True, "perceptual": True}, (1, 2), 3)])
+def test_score_candidates_parity_with_maps(S, O, img256_alpha, flags, slot, n):
+    import torch
+    g, o = pair(S, O, img256_alpha, 8, 15, **flags)
+    o.initialize_tiles()
+    o.recalculate_palettes()
+    sync_state(g, o)
+    cand = S.random_candidates(5, slot[0] * 100 + slot[1], n)
+    cand[0] = o.palette[slot[0] * 15 + slot[1]]       # the incumbent colour itself
+    cand[1] = o.palette[slot[0] * 15 + (slot[1] + 1) % 15]  # duplicate of a neighbouring entry: tie-break by index
+    eo, mo = o.score_candidates(slot[0], slot[1], cand, want_maps=True)
+    d_c = torch.from_numpy(cand).cuda()
+    d_e = torch.zeros(n, dtype=torch.float64, device="cuda")
+    d_m = torch.zeros((n, 256, 256), dtype=torch.uint8, device="cuda")
+    g.score_candidates_device(slot[0], slot[1], d_c.data_ptr(), n, d_e.data_ptr(), d_m.data_ptr())
+    g.sync()
+    assert np.array_equal(d_m.cpu().numpy(), mo)                   # indices bit-exact
+    assert rel(d_e.cpu().numpy(), eo) < REL_ERR
+    assert rel(g.score_candidates(slot[0], slot[1], cand), eo) < REL_ERR
+    assert rel(eo[0], o.error()) == 0.0 and rel(g.score_candidates(slot[0], slot[1], cand[:1])[0], g.error()) == 0.0
+    assert np.array_equal(g.palette, o.palette) and np.array_equal(g.palette_map, o.palette_map)  # state untouched
+    g.close()
+
+
+def test_chunking_does_not_change_results(S, O, img256):
+    g, o = pair(S, O, img256, 8, 15)
+    o.initialize_tiles()
+    o.recalculate_palettes()
+    sync_state(g, o)
+    cand = S.random_candidates(9, 9, 70)
+    g.set_chunk(256)
+    a = g.score_candidates(4, 4, cand)
+    g.set_chunk(7)
+    b = g.score_candidates(4, 4, cand)
+    g.set_chunk(64)
+    c = g.score_candidates(4, 4, cand)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert rel(a[:5], o.score_candidates(4, 4, cand[:5])) < REL_ERR
+    assert g.score_candidates(4, 4, cand[:0]).size == 0
+    with pytest.raises(S.SnesImageError):
+        g.score_candidates(8, 0, cand)
+    with pytest.raises(S.SnesImageError):
+        g.score_candidates(0, 15, cand)
+    g.close()
+
+
+@pytest.mark.parametrize("h,count,size", [(8, 1, 3), (16, 2, 3), (32, 2, 7), (64, 4, 7), (128, 8, 15)])
+def test_small_heights(S, O, h, count, size):
+    from snesimage_amd.synth import synth_image
+    img = synth_image(0x5EED0010 + h, 256, h, 0)
+    g, o = pair(S, O, img, count, size)
+    g.initialize_tiles()
+    o.initialize_tiles()
+    g.recalculate_palettes()
+    o.recalculate_palettes()
+    assert np.array_equal(g.palette, o.palette) and np.array_equal(g.palette_map, o.palette_map)
+    cand = S.random_candidates(2, h, 5)
+    assert rel(g.score_candidates(count - 1, size - 1, cand), o.score_candidates(count - 1, size - 1, cand)) < REL_ERR
+    g.close()
+
+
+def test_single_entry_subpalette_and_max_palette(S, O, img256):
+    g, o = pair(S, O, img256, 8, 1)
+    o.initialize_tiles()
+    sync_state(g, o)
+    cand = S.random_candidates(3, 3, 4)
+    eo, mo = o.score_candidates(3, 0, cand, want_maps=True)
+    assert rel(g.score_candidates(3, 0, cand), eo) < REL_ERR
+    g.close()
+    g, o = pair(S, O, img256, 11, 23)  # 253 colours: the largest palette the packed index allows
+    o.initialize_tiles()
+    o.recalculate_palettes()
+    sync_state(g, o)
+    g.optimize()
+    assert np.array_equal(g.palette_map, o.palette_map)
+    cand = S.random_candidates(3, 4, 3)
+    assert rel(g.score_candidates(10, 22, cand), o.score_candidates(10, 22, cand)) < REL_ERR
+    g.close()
+    with pytest.raises(S.SnesImageError):
+        S.OptimizedImage(img256, 16, 16)
+
+
+def test_quirk_component_32(S, O, img256):
+    """Q3: a k-means centre >= 252 rounds to component 32, which wraps in as_rgba."""
+    g, o = pair(S, O, img256, 2, 3)
+    o.initialize_tiles()
+    pal = o.palette
+    pal[1] = [32, 5, 32]
+    o.palette = pal
+    o.optimize()
+    sync_state(g, o)
+    g.optimize()
+    assert np.array_equal(g.palette_map, o.palette_map)
+    assert rel(g.error(), o.error()) < REL_ERR
+    assert np.array_equal(g.palette_u16, o.palette_u16) and g.as_json() == o.as_json()
+    g.close()
+
+
+# ---- optimizer steps ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("flags", [{}, {"dither": True}, {"perceptual": True}])
+def test_step_trajectory_matches_oracle(S, O, flags):
+    from snesimage_amd.synth import synth_image
+    img = synth_image(0x5EED0002, 256, 64, 1 if flags else 0)
+    g, o = pair(S, O, img, 2, 3, **flags)
+    g.initialize_tiles()
+    o.initialize_tiles()
+    g.recalculate_palettes()
+    o.recalculate_palettes()
+    sched = S.schedule(2, 3, 30)
+    for i in [0, 1, 2, 3, 4, 5, 24, 25, 26, 27]:  # random calls, then the first channel calls
+        method, p, idx, ch, _ = sched[i]
+        eg, bg = g.step(method, p, idx, ch, 1, i, 16 if method == 0 else 0)
+        eo, bo = o.step(method, p, idx, ch, 1, i, 16 if method == 0 else 0)
+        assert np.array_equal(bg, bo), i
+        assert rel(eg, eo) < REL_ERR
+        assert np.array_equal(g.palette, o.palette) and np.array_equal(g.palette_map, o.palette_map)
+    assert g.as_json() == o.as_json()
+    g.close()
+
+
+def test_nes_steps(S, O):
+    from snesimage_amd.synth import synth_image
+    img = synth_image(0x5EED0003, 256, 64)
+    g, o = pair(S, O, img, 2, 3, nes=True)
+    g.initialize_tiles()
+    o.initialize_tiles()
+    g.recalculate_palettes()
+    o.recalculate_palettes()
+    for i, (p, idx) in enumerate([(0, 0), (1, 2), (0, 1)]):
+        eg, bg = g.step(S.METHOD_NES, p, idx, 0, 1, i)
+        eo, bo = o.step(2, p, idx, 0, 1, i)
+        assert np.array_equal(bg, bo) and rel(eg, eo) < REL_ERR
+    assert np.array_equal(g.palette, o.palette)
+    g.close()
+
+
+def test_split_phase_step_equals_plain_step(S, O, img256):
+    """step_begin / (min-reduce) / step_commit with 2 shards on one GPU == step()."""
+    import torch
+    ref = S.OptimizedImage(img256, 8, 15)
+    ref.initialize_tiles()
+    ref.recalculate_palettes()
+    shards = []
+    for _ in range(2):
+        s = S.OptimizedImage(img256, 8, 15)
+        s.tile_palettes = ref.tile_palettes
+        s.palette = ref.palette
+        s.optimize()
+        shards.append(s)
+    for i, (p, idx) in enumerate([(0, 0), (3, 7), (0, 0)]):
+        e_ref, b_ref = ref.step(S.METHOD_RANDOM, p, idx, 0, 4, i, 40)
+        bufs = [torch.empty(40, dtype=torch.float64, device="cuda") for _ in range(2)]
+        for r, s in enumerate(shards):
+            s.step_begin(S.METHOD_RANDOM, p, idx, 0, 4, i, 40, r, 2, bufs[r].data_ptr())
+            s.sync()
+        assert torch.isinf(bufs[0][1::2]).all() and torch.isinf(bufs[1][0::2]).all()
+        red = torch.minimum(bufs[0], bufs[1])  # what the RCCL min-all-reduce produces
+        for s in shards:
+            s.step_commit(red.data_ptr())
+            e, b, _ = s.last_step()
+            assert e == e_ref and np.array_equal(b, b_ref)
+            assert np.array_equal(s.palette, ref.palette) and np.array_equal(s.palette_map, ref.palette_map)
+    for s in shards:
+        s.close()
+    ref.close()
+
+
+# ---- size-independent properties at BASELINE's full size ---------------------------------------------
+def test_exact_reconstruction_scores_zero(S):
+    rng = np.random.default_rng(21)
+    pal5 = rng.integers(0, 32, size=(8, 15, 3)).astype(np.uint8)
+    tp = rng.integers(0, 8, size=1024).astype(np.uint8)
+    idx = rng.integers(0, 15, size=(256, 256))
+    img = np.zeros((256, 256, 4), np.uint8)
+    sub = tp.reshape(32, 32).repeat(8, 0).repeat(8, 1)
+    c5 = pal5[sub, idx].astype(np.uint16)
+    img[..., :3] = (c5 * 8 + c5 // 4).astype(np.uint8)
+    img[..., 3] = 255
+    g = S.OptimizedImage(img, 8, 15)
+    g.tile_palettes = tp
+    g.palette = pal5.reshape(-1, 3)
+    g.optimize()
+    assert g.error() == 0.0                       # 100 - 100 exactly
+    assert np.array_equal(g.as_rgba(), img)
+    e = g.score_candidates(0, 0, [[(int(pal5[0, 0, 0]) + 9) % 32, 3, 3]])
+    assert e[0] >= 0.0
+    g.close()
+
+
+def test_large_batch_is_consistent_and_monotone_under_commit(S, img256):
+    g = S.OptimizedImage(img256, 8, 15)
+    g.initialize_tiles()
+    g.recalculate_palettes()
+    e0 = g.error()
+    cand = S.random_candidates(77, 1, 2048)
+    errs = g.score_candidates(6, 2, cand)
+    assert np.isfinite(errs).all() and (errs >= 0).all()
+    # duplicates in the candidate list score identically (checksum-of-duplicates property)
+    _, first, inv = np.unique(cand, axis=0, return_index=True, return_inverse=True)
+    assert np.array_equal(errs, errs[first][inv.reshape(-1)])
+    e1, best = g.step(S.METHOD_RANDOM, 6, 2, 0, 77, 1, 2048)
+    assert e1 == min(e0, errs.min()) and (e1 == e0 or np.array_equal(best, cand[int(np.argmin(errs))]))
+    assert g.error() == e1
+    g.close()
+
+
+# ---- golden fixtures ---------------------------------------------------------------------------------
+def _golden():
+    with open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")) as f:
+        return json.load(f)["cases"]
+
+
+@pytest.mark.parametrize("case", _golden(), ids=lambda c: c["name"])
+def test_gpu_matches_golden(S, case):
+    from snesimage_amd.synth import synth_image
+    import torch
+    g_ = case
+    img = synth_image(g_["seed"], 256, g_["h"], g_["variant"])
+    g = S.OptimizedImage(img, g_["count"], g_["size"], dither=g_["dither"], perceptual=g_["perceptual"], nes=g_["nes"])
+    g.initialize_tiles()
+    assert g.palette.reshape(-1).tolist() == g_["init_palette"]
+    assert hashlib.sha256(g.tile_palettes.tobytes()).hexdigest() == g_["init_tile_palettes_sha"]
+    assert hashlib.sha256(g.palette_map.tobytes()).hexdigest() == g_["init_map_sha"]
+    g.recalculate_palettes()
+    assert g.palette.reshape(-1).tolist() == g_["palette"]
+    assert hashlib.sha256(g.palette_map.tobytes()).hexdigest() == g_["map_sha"]
+    assert rel(g.error(), float.fromhex(g_["error_hex"])) < REL_ERR
+    cand = S.random_candidates(1, 42, g_["ncand"])
+    n = g_["ncand"]
+    d_c = torch.from_numpy(cand).cuda()
+    d_e = torch.zeros(n, dtype=torch.float64, device="cuda")
+    d_m = torch.zeros((n, g_["h"], 256), dtype=torch.uint8, device="cuda")
+    g.score_candidates_device(g_["slot"][0], g_["slot"][1], d_c.data_ptr(), n, d_e.data_ptr(), d_m.data_ptr())
+    g.sync()
+    assert hashlib.sha256(d_m.cpu().numpy().tobytes()).hexdigest() == g_["cand_maps_sha"]
+    assert rel(d_e.cpu().numpy(), [float.fromhex(h) for h in g_["cand_errors_hex"]]) < REL_ERR
+    err, best = g.step(2 if g_["nes"] else 0, g_["slot"][0], g_["slot"][1], 0, 1, 7)
+    assert best.tolist() == g_["step_best"] and rel(err, float.fromhex(g_["step_error_hex"])) < REL_ERR
+    assert hashlib.sha256(g.as_json().encode()).hexdigest() == g_["json_sha"]
+    g.close()

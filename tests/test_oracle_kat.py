@@ -1,0 +1,340 @@
+"""Known-answer tests that pin the CPU oracle.
+
+The reference ships no tests or fixtures, so the pins are (a) the first-party known answers that
+follow from /root/reference/src/lib.rs alone and (b) externally published vectors for the
+third-party algorithms (Sharma's CIEDE2000 table, canonical sRGB->Lab values).  Run on CPU.
+"""
+import json
+import math
+
+import numpy as np
+import pytest
+
+
+# ---- KAT 1: as_rgba expansion and as_u16 (lib.rs:662-669, 679-681) ---------------------------------
+def test_expand_and_u16(O):
+    for v, e in [(0, 0), (1, 8), (15, 123), (16, 132), (31, 255)]:
+        assert O.snes_as_rgba([v, v, v]).tolist() == [e, e, e, 255]
+    assert O.snes_as_u16([31, 0, 0]) == 31
+    assert O.snes_as_u16([0, 31, 0]) == 992
+    assert O.snes_as_u16([0, 0, 31]) == 31744
+    # quirk Q3: a component of 32 wraps in u8 arithmetic (release build): 32*8 = 0 (mod 256), + 32/4 = 8
+    assert O.snes_as_rgba([32, 0, 0]).tolist() == [8, 0, 0, 255]
+
+
+# ---- KAT 2: redmean distance (lib.rs:1080-1088) ---------------------------------------------------
+def test_redmean_known_answers(O):
+    assert O.distance_red_mean([0, 0, 0], [255, 255, 255]) == 764.8339663572415
+    assert O.distance_red_mean([255, 0, 0], [0, 0, 0]) == 403.0328746478071
+    assert O.distance_red_mean([0, 255, 0], [0, 0, 0]) == 510.0
+    assert O.distance_red_mean([0, 0, 255], [0, 0, 0]) == 441.3853147690235
+
+
+def test_redmean_symmetry_and_integer_key(O):
+    rng = np.random.default_rng(1)
+    cols = rng.integers(0, 256, size=(400, 3)).astype(np.uint8)
+    d = [O.distance_red_mean(cols[i], cols[i + 1]) for i in range(0, 398)]
+    k = [O.red_mean_key(cols[i], cols[i + 1]) for i in range(0, 398)]
+    for i in range(0, 398):
+        assert O.distance_red_mean(cols[i + 1], cols[i]) == d[i]
+        assert math.sqrt(k[i] / 512.0) == d[i]  # key = 512 * pre-sqrt value, exactly
+    # the u32 key orders pairs exactly like the f64 distance, ties included
+    order_d = np.argsort(np.array(d), kind="stable")
+    order_k = np.argsort(np.array(k, dtype=np.uint64), kind="stable")
+    assert np.array_equal(order_d, order_k)
+    assert max(k) < 2 ** 31
+    assert O.red_mean_key([255, 255, 255], [0, 0, 0]) == 299505150
+
+
+# ---- KAT 3: argmin tie-break (lib.rs:788-791) ------------------------------------------------------
+def test_argmin_first_wins(O):
+    entries = [[5, 5, 5], [5, 5, 5], [1, 1, 1]]
+    assert O.closest_color_index(entries, [41.0, 41.0, 41.0]) == 0
+    assert O.closest_color_index([[1, 1, 1], [5, 5, 5], [5, 5, 5]], [41.0, 41.0, 41.0]) == 1
+    # clamp then round half away from zero (lib.rs:773-778)
+    assert O.closest_color_index([[0, 0, 0], [31, 31, 31]], [300.0, 260.0, 999.0]) == 1
+    assert O.closest_color_index([[0, 0, 0], [31, 31, 31]], [-5.0, -0.4, 0.4]) == 0
+
+
+def test_initialize_tiles_gives_zero_map(O, img256):
+    o = O.OracleImage(img256, 8, 15)
+    o.initialize_tiles()
+    pal = o.palette.reshape(8, 15, 3)
+    assert all((pal[i] == pal[i][0]).all() for i in range(8))  # lib.rs:181-183
+    assert not o.palette_map.any()                              # duplicates -> lowest index
+
+
+# ---- KAT 4: no-dither optimize == per-pixel argmin (lib.rs:429) -------------------------------------
+def test_no_dither_is_independent_argmin(O, img256_alpha):
+    o = O.OracleImage(img256_alpha, 4, 7)
+    o.initialize_tiles()
+    o.recalculate_palettes()
+    pal, tp, m = o.palette.reshape(4, 7, 3), o.tile_palettes, o.palette_map
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        x, y = int(rng.integers(0, 256)), int(rng.integers(0, 256))
+        sub = tp[(y // 8) * 32 + x // 8]
+        want = O.closest_color_index(pal[sub], img256_alpha[y, x, :3].astype(np.float64))
+        assert m[y, x] == (want if img256_alpha[y, x, 3] > 0 else 0)
+
+
+# ---- KAT 5: dither recurrence on a constant image (lib.rs:432, 477-496) ----------------------------
+def test_dither_constant_image(O):
+    img = np.zeros((8, 256, 4), np.uint8)
+    img[..., :3] = 100
+    img[..., 3] = 255
+    o = O.OracleImage(img, 1, 2, dither=True)
+    o.palette = [[12, 12, 12], [13, 13, 13]]  # 8-bit 99 and 107
+    o.optimize()
+    m = o.palette_map
+    # first pixel: target 100 -> nearer 99 (index 0); its error +1 diffuses 0.8*7/16 = 0.35 to the right:
+    # target 100.35 -> rounds to 100 -> still index 0, error 1.35 -> next 100.4725 ... independent replay:
+    err = np.zeros((8, 256))
+    for y in range(8):
+        for x in range(256):
+            t = 100.0 + err[y, x]
+            q = float(np.floor(min(max(t, 0.0), 255.0) + 0.5))
+            idx = 0 if abs(q - 99) <= abs(q - 107) else 1
+            assert m[y, x] == idx, (x, y)
+            e = t - (99.0 if idx == 0 else 107.0)
+            if x + 1 < 256:
+                err[y, x + 1] += e * 0.8 * (7.0 / 16.0)
+            if y + 1 < 8:
+                if x > 0:
+                    err[y + 1, x - 1] += e * 0.8 * (3.0 / 16.0)
+                err[y + 1, x] += e * 0.8 * (5.0 / 16.0)
+                if x + 1 < 256:
+                    err[y + 1, x + 1] += e * 0.8 * (1.0 / 16.0)
+    assert m.any() and not m.all()
+
+
+def test_dither_transparent_forwards_error(O):
+    img = np.zeros((8, 256, 4), np.uint8)
+    img[..., :3] = 100
+    img[..., 3] = 255
+    img[0, 1, 3] = 0  # transparent second pixel
+    o = O.OracleImage(img, 1, 2, dither=True)
+    o.palette = [[12, 12, 12], [13, 13, 13]]
+    o.optimize()
+    assert o.palette_map[0, 1] == 0
+    # pixel (2,0) receives 0.35 * 0.35 of pixel 0's error through the transparent pixel (lib.rs:469-474)
+    t = 100.0 + (100.0 - 99.0) * 0.8 * (7 / 16) * 0.8 * (7 / 16)
+    assert o.palette_map[0, 2] == (0 if abs(round(t) - 99) <= abs(round(t) - 107) else 1)
+
+
+# ---- KAT 6: error() (lib.rs:503-548) ---------------------------------------------------------------
+def test_error_identical_is_zero(O, img256):
+    assert O.ssimulacra2_rgba(img256, img256) == 100.0
+    q = (img256 // 8) * 8 + (img256 // 8) // 4  # every colour exactly representable in BGR555
+    q[..., 3] = 255
+    assert O.ssimulacra2_rgba(q, q) == 100.0
+
+
+def test_error_nonnegative_and_transparent_counts(O, img256, img256_alpha):
+    o = O.OracleImage(img256_alpha, 4, 7)
+    o.initialize_tiles()
+    o.recalculate_palettes()
+    e_alpha = o.error()
+    assert e_alpha > 0
+    # reconstruction keeps transparent pixels black (lib.rs:570-572) while the source keeps their RGB
+    rgba = o.as_rgba()
+    assert not rgba[96:160, 96:160].any()
+
+
+def test_ssim2_weights_count():
+    # the 108 weights are transcribed once in the oracle and once in the kernels; they must agree
+    import re
+    a = open("oracle/snes_oracle.cpp").read()
+    b = open("snesimage_amd/csrc/kernels.hpp").read()
+    wa = re.search(r"SSIM2_WEIGHT\[108\] = \{(.*?)\};", a, re.S).group(1)
+    wb = re.search(r"kSsim2Weight\[108\] = \{(.*?)\};", b, re.S).group(1)
+    fa = [float(t) for t in wa.replace("\n", " ").split(",") if t.strip()]
+    fb = [float(t) for t in wb.replace("\n", " ").split(",") if t.strip()]
+    assert len(fa) == 108 and fa == fb
+
+
+# ---- KAT 7: JSON shape (lib.rs:579-625) ------------------------------------------------------------
+def test_json_shape(O, img256_alpha):
+    o = O.OracleImage(img256_alpha, 3, 7)
+    o.initialize_tiles()
+    o.recalculate_palettes()
+    text = o.as_json()
+    doc = json.loads(text)
+    assert list(doc.keys()) == ["palette", "tile_palettes", "tiles"]  # serde_json sorts keys
+    assert " " not in text and "\n" not in text                        # to_string() is compact
+    assert len(doc["palette"]) == 16 * 3
+    pal = o.palette_u16.reshape(3, 7)
+    for p in range(3):
+        row = doc["palette"][16 * p:16 * p + 16]
+        assert row[0] == 0 and row[8:] == [0] * 8 and row[1:8] == pal[p].tolist()
+    assert len(doc["tiles"]) == 1024 and all(len(t) == 64 for t in doc["tiles"])
+    assert doc["tile_palettes"] == o.tile_palettes.tolist()
+    m = o.palette_map
+    tile = doc["tiles"][12 * 32 + 12]  # inside the transparent square
+    assert tile == [0] * 64
+    t0 = doc["tiles"][0]
+    assert t0 == [int(m[y, x]) + 1 for y in range(8) for x in range(8)]
+
+
+# ---- KAT 8: slot schedule (lib.rs:890, 917-932) ----------------------------------------------------
+def test_schedule(O):
+    s = O.schedule(2, 3, 6 * 4 + 18 + 2)
+    # steps 0-3: six random calls each, slots in (palette, index) order
+    for step in range(4):
+        calls = s[6 * step:6 * step + 6]
+        assert [c[0] for c in calls] == [0] * 6
+        assert [(c[1], c[2]) for c in calls] == [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (1, 2)]
+        assert all(c[4] == step and c[3] == 0 for c in calls)
+    # step 4: 18 channel calls, three channels per slot
+    calls = s[24:42]
+    assert [c[0] for c in calls] == [1] * 18
+    assert [(c[1], c[2], c[3]) for c in calls] == [(p, i, ch) for p in range(2) for i in range(3) for ch in range(3)]
+    assert s[42][0] == 0 and s[42][4] == 5
+    assert all(c[0] == 2 for c in O.schedule(2, 3, 10, nes=True))
+
+
+# ---- KAT 9: acceptance rule (lib.rs:216, 250, 302) -------------------------------------------------
+def test_acceptance_strict_and_nes(O):
+    from snesimage_amd.synth import synth_image
+    img = synth_image(0x5EED0002, 256, 64)
+    o = O.OracleImage(img, 2, 3)
+    o.initialize_tiles()
+    o.recalculate_palettes()
+    before, e0 = o.palette.copy(), o.error()
+    # channel sweep always contains the incumbent value itself: equal error must NOT be accepted as a change,
+    # and the result can never be worse than the incumbent
+    e1, best = o.step(1, 0, 1, channel=2)
+    assert e1 <= e0
+    if e1 == e0:
+        assert np.array_equal(o.palette, before)
+    # NES method ignores the incumbent: the slot always ends on a table colour
+    o2 = O.OracleImage(img, 2, 3, nes=True)
+    o2.initialize_tiles()
+    o2.recalculate_palettes()
+    _, best = o2.step(2, 1, 2)
+    table = [O.nes_color(i).tolist() for i in range(56)]
+    assert best.tolist() in table
+    assert O.nes_color(13).tolist() == [0, 0, 0] == O.nes_color(27).tolist()
+    assert O.nes_color(28).tolist() == [31, 31, 31] == O.nes_color(42).tolist()
+    assert O.nes_color(99).tolist() == [0, 0, 0]
+
+
+# ---- third-party restatements: external known answers ------------------------------------------------
+SHARMA = """50.0000 2.6772 -79.7751 50.0000 0.0000 -82.7485 2.0425
+50.0000 3.1571 -77.2803 50.0000 0.0000 -82.7485 2.8615
+50.0000 2.8361 -74.0200 50.0000 0.0000 -82.7485 3.4412
+50.0000 -1.3802 -84.2814 50.0000 0.0000 -82.7485 1.0000
+50.0000 -1.1848 -84.8006 50.0000 0.0000 -82.7485 1.0000
+50.0000 -0.9009 -85.5211 50.0000 0.0000 -82.7485 1.0000
+50.0000 0.0000 0.0000 50.0000 -1.0000 2.0000 2.3669
+50.0000 -1.0000 2.0000 50.0000 0.0000 0.0000 2.3669
+50.0000 2.4900 -0.0010 50.0000 -2.4900 0.0009 7.1792
+50.0000 2.4900 -0.0010 50.0000 -2.4900 0.0010 7.1792
+50.0000 2.4900 -0.0010 50.0000 -2.4900 0.0011 7.2195
+50.0000 2.4900 -0.0010 50.0000 -2.4900 0.0012 7.2195
+50.0000 -0.0010 2.4900 50.0000 0.0009 -2.4900 4.8045
+50.0000 -0.0010 2.4900 50.0000 0.0010 -2.4900 4.8045
+50.0000 -0.0010 2.4900 50.0000 0.0011 -2.4900 4.7461
+50.0000 2.5000 0.0000 50.0000 0.0000 -2.5000 4.3065
+50.0000 2.5000 0.0000 73.0000 25.0000 -18.0000 27.1492
+50.0000 2.5000 0.0000 61.0000 -5.0000 29.0000 22.8977
+50.0000 2.5000 0.0000 56.0000 -27.0000 -3.0000 31.9030
+50.0000 2.5000 0.0000 58.0000 24.0000 15.0000 19.4535
+50.0000 2.5000 0.0000 50.0000 3.1736 0.5854 1.0000
+50.0000 2.5000 0.0000 50.0000 3.2972 0.0000 1.0000
+50.0000 2.5000 0.0000 50.0000 1.8634 0.5757 1.0000
+50.0000 2.5000 0.0000 50.0000 3.2592 0.3350 1.0000
+60.2574 -34.0099 36.2677 60.4626 -34.1751 39.4387 1.2644
+63.0109 -31.0961 -5.8663 62.8187 -29.7946 -4.0864 1.2630
+61.2901 3.7196 -5.3901 61.4292 2.2480 -4.9620 1.8731
+35.0831 -44.1164 3.7933 35.0232 -40.0716 1.5901 1.8645
+22.7233 20.0904 -46.6940 23.0331 14.9730 -42.5619 2.0373
+36.4612 47.8580 18.3852 36.2715 50.5065 21.2231 1.4146
+90.8027 -2.0831 1.4410 91.1528 -1.6435 0.0447 1.4441
+90.9257 -0.5406 -0.9208 88.6381 -0.8985 -0.7239 1.5381
+6.7747 -0.2908 -2.4247 5.8714 -0.0985 -2.2286 0.6377
+2.0776 0.0795 -1.1350 0.9033 -0.0636 -0.5514 0.9082"""
+
+
+def test_ciede2000_sharma_table(O):
+    """Sharma, Wu, Dalal (2005) CIEDE2000 test data: 34 pairs, published to 4 decimals."""
+    for line in SHARMA.splitlines():
+        v = [float(t) for t in line.split()]
+        assert abs(O.ciede2000(v[0:3], v[3:6]) - v[6]) < 6e-4, v
+        assert abs(O.ciede2000(v[3:6], v[0:3]) - v[6]) < 6e-4, v
+
+
+def test_srgb_to_lab_primaries(O):
+    ref = {(255, 255, 255): (100.0, 0.0, 0.0), (255, 0, 0): (53.2408, 80.0925, 67.2032), (0, 255, 0): (87.7347, -86.1827, 83.1793),
+           (0, 0, 255): (32.2970, 79.1875, -107.8602), (0, 0, 0): (0.0, 0.0, 0.0)}
+    for rgb, lab in ref.items():
+        got = O.srgb8_to_lab(list(rgb))
+        assert np.allclose(got, lab, atol=2e-2), (rgb, got)
+    back = O.lab_to_srgb8([53.2408, 80.0925, 67.2032])
+    assert back.tolist() == [255, 0, 0]
+    assert O.lab_to_srgb8([100.0, 0.0, 0.0]).tolist() == [255, 255, 255]
+
+
+def test_blur_is_normalised_truncated_cosine(O):
+    n2, d1, fir = O.blur_constants()
+    assert abs(float(fir.sum()) - 1.0) < 1e-5 and np.allclose(fir, fir[::-1], atol=1e-6)
+    plane = np.zeros((32, 32), np.float32)
+    plane[16, 16] = 1.0
+    out = O.blur_plane(plane)
+    assert np.allclose(out[16, 12:21], fir * fir[4], atol=1e-6)   # separable, support [-4, 4]
+    assert abs(float(out.sum()) - 1.0) < 1e-4
+    assert np.abs(out[:, :10]).max() < 1e-6                        # recurrence cancels outside the window
+    ones = np.ones((40, 40), np.float32)
+    assert np.allclose(O.blur_plane(ones)[10:30, 10:30], 1.0, atol=1e-5)
+
+
+def test_kmeans_restatement(O):
+    pts = np.array([[0, 0, 0], [10, 10, 10], [1, 1, 1], [11, 11, 11], [0, 1, 0], [10, 11, 10]], np.float64)
+    centres, assign, iters = O.kmeans(pts, 2)
+    assert assign.tolist() == [0, 1, 0, 1, 0, 1]   # initial centres = first k points
+    assert np.allclose(centres[0], [1 / 3, 2 / 3, 1 / 3]) and np.allclose(centres[1], [31 / 3, 32 / 3, 31 / 3])
+    with pytest.raises(RuntimeError):
+        O.kmeans(pts[:2], 2)                       # cogset asserts 2 <= k < n
+    # duplicate leading points -> an empty cluster -> NaN centre that is never re-assigned
+    dup = np.array([[5, 5, 5], [5, 5, 5], [9, 9, 9], [1, 1, 1]], np.float64)
+    c, a, _ = O.kmeans(dup, 2)
+    assert np.isnan(c[1]).all() and (a == 0).all()
+
+
+def test_det_math_accuracy(O):
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-30, 30, 4000).astype(np.float32)
+    assert np.max(np.abs(O.det_math(0, x).astype(np.float64) - np.sin(x.astype(np.float64)))) < 1e-7
+    assert np.max(np.abs(O.det_math(1, x).astype(np.float64) - np.cos(x.astype(np.float64)))) < 1e-7
+    xe = rng.uniform(-100, 0, 4000).astype(np.float32)
+    ref = np.exp(xe.astype(np.float64))
+    assert np.max(np.abs(O.det_math(2, xe).astype(np.float64) - ref) / np.maximum(ref, 1e-38)) < 1e-6
+    xc = rng.uniform(0, 4, 4000).astype(np.float32)
+    assert np.array_equal(O.det_math(3, xc), np.cbrt(xc.astype(np.float64)).astype(np.float32))
+    ya, xa = rng.uniform(-5, 5, 4000).astype(np.float32), rng.uniform(-5, 5, 4000).astype(np.float32)
+    assert np.max(np.abs(O.det_math(4, xa, ya).astype(np.float64) - np.arctan2(ya.astype(np.float64), xa.astype(np.float64)))) < 3e-7
+
+
+# ---- golden fixtures (self-generated; tests/golden/make_golden.py) ------------------------------------
+def _golden():
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")) as f:
+        return json.load(f)["cases"]
+
+
+@pytest.mark.parametrize("name", ["cfg2_8x15_rgb", "small_256x64_4x7", "nes_2x3"])
+def test_oracle_matches_golden(O, name):
+    import hashlib
+    from snesimage_amd.synth import synth_image
+    g = next(c for c in _golden() if c["name"] == name)
+    img = synth_image(g["seed"], 256, g["h"], g["variant"])
+    o = O.OracleImage(img, g["count"], g["size"], dither=g["dither"], perceptual=g["perceptual"], nes=g["nes"])
+    o.initialize_tiles()
+    assert o.palette.reshape(-1).tolist() == g["init_palette"]
+    assert hashlib.sha256(o.tile_palettes.tobytes()).hexdigest() == g["init_tile_palettes_sha"]
+    o.recalculate_palettes()
+    assert o.palette.reshape(-1).tolist() == g["palette"]
+    assert hashlib.sha256(o.palette_map.tobytes()).hexdigest() == g["map_sha"]
+    assert float(o.error()).hex() == g["error_hex"]
+    errs = o.score_candidates(g["slot"][0], g["slot"][1], O.random_candidates(1, 42, g["ncand"]))
+    assert [float(e).hex() for e in errs] == g["cand_errors_hex"]
