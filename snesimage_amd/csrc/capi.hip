@@ -3,6 +3,7 @@
 #include "../../include/snesimage_hip.h"
 #include "kernels.hpp"
 #include "kernels_opt.hpp"
+#include "kernels_fast.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -99,7 +100,9 @@ struct snesimage_ctx {
 
     // device state
     uint8_t *d_orig = nullptr, *d_tile_pal = nullptr, *d_colors = nullptr, *d_map = nullptr;
-    unsigned long long *d_pack = nullptr, *d_packT = nullptr;
+    unsigned long long *d_pack = nullptr, *d_packT = nullptr, *d_packC4 = nullptr, *d_packR4 = nullptr;
+    float *d_img1C4 = nullptr, *d_img1R4 = nullptr, *d_mu1R4 = nullptr, *d_s11R4 = nullptr; // blocked copies for the fast kernels
+    int fast_mask = 0; // bit s: scale s has width and height multiples of 64
     float *d_eotf = nullptr, *d_lab_eotf = nullptr;
     uint32_t *d_pal_rgb8 = nullptr; float *d_pal_lin = nullptr, *d_pal_xyb = nullptr, *d_pal_lab = nullptr;
     float *d_lin0 = nullptr, *d_img1 = nullptr, *d_img1T = nullptr, *d_mu1 = nullptr, *d_s11 = nullptr;
@@ -193,6 +196,13 @@ int32_t ensure_source(snesimage_ctx *c) {
         int ppv = 256 / G.sw[s];
         hipLaunchKernelGGL((k_vpass<false, true, false>), dim3((3 + ppv - 1) / ppv), dim3(256), 0, c->stream, Vp);
     }
+    for (int s = 0; s < G.nscales; s++)
+        if (c->fast_mask & (1 << s)) {
+            const int N = G.sw[s] * G.sh[s];
+            hipLaunchKernelGGL(k_relayout, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_img1 + G.src_off[s], G.sw[s], G.sh[s], c->d_img1R4 + G.src_off[s], c->d_img1C4 + G.src_off[s]);
+            hipLaunchKernelGGL(k_relayout, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_mu1 + G.src_off[s], G.sw[s], G.sh[s], c->d_mu1R4 + G.src_off[s], (float *)nullptr);
+            hipLaunchKernelGGL(k_relayout, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_s11 + G.src_off[s], G.sw[s], G.sh[s], c->d_s11R4 + G.src_off[s], (float *)nullptr);
+        }
     if (c->perceptual)
         hipLaunchKernelGGL(k_pixel_lab, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, c->d_orig, c->d_lab_eotf, (int)c->W, (int)c->H, c->d_labpx, c->d_labpxT);
     HIPCHK(hipGetLastError());
@@ -205,7 +215,7 @@ int32_t run_prep(snesimage_ctx *c, int mode, int sp, int si) {
     CHECK(ensure_tables(c));
     if (c->perceptual) CHECK(ensure_source(c));
     PrepParams P{};
-    P.orig = c->d_orig; P.tile_pal = c->d_tile_pal; P.pal_rgb8 = c->d_pal_rgb8; P.map = c->d_map; P.pack = c->d_pack; P.packT = c->d_packT;
+    P.orig = c->d_orig; P.tile_pal = c->d_tile_pal; P.pal_rgb8 = c->d_pal_rgb8; P.map = c->d_map; P.pack = c->d_pack; P.packT = c->d_packT; P.packC4 = c->d_packC4; P.packR4 = c->d_packR4;
     P.labpx = c->d_labpx; P.pal_lab = c->d_pal_lab;
     P.W = (int)c->W; P.H = (int)c->H; P.sub_size = (int)c->sub_size; P.ncol = c->ncol; P.mode = mode; P.sp = sp; P.si = si; P.perceptual = c->perceptual ? 1 : 0;
     hipLaunchKernelGGL(k_prep, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, P);
@@ -245,35 +255,57 @@ int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double
     }
     if (G.nscales > 1) {
         DownParams D{}; D.G = G; D.pack = c->d_pack; D.pal_lin = c->d_pal_lin; D.cand_tab = c->d_cand_tab; D.cand_lab = c->d_cand_lab; D.labpx = c->d_labpx;
-        D.work = c->d_work; D.ncol = c->ncol; D.perceptual = c->perceptual ? 1 : 0; D.use_maps = use_maps ? 1 : 0; D.maps = c->d_maps; D.tile_pal = c->d_tile_pal; D.sub_size = (int)c->sub_size;
+        D.work = c->d_work; D.ncol = c->ncol; D.perceptual = c->perceptual ? 1 : 0; D.use_maps = use_maps ? 1 : 0; D.fast_mask = c->fast_mask & ~1; D.maps = c->d_maps; D.tile_pal = c->d_tile_pal; D.sub_size = (int)c->sub_size;
         hipLaunchKernelGGL(k_downscale_chain<true>, dim3((G.W / 32) * ((G.H + 31) / 32), nc), dim3(256), 0, c->stream, D);
     }
+    const bool fast0 = (c->fast_mask & 1) && !c->perceptual && !use_maps; // scale 0 takes its pixels from the pack (RGB keys)
+    auto is_fast = [&](int s) { return s == 0 ? fast0 : ((c->fast_mask >> s) & 1) != 0; };
+    auto fast_params = [&](int s) {
+        FastParams F{}; F.G = G; F.K = c->K; F.s = s; F.npairs = npairs; F.ncol = c->ncol;
+        F.packC4 = c->d_packC4; F.packR4 = c->d_packR4; F.pal_xyb = c->d_pal_xyb; F.cand_tab = c->d_cand_tab;
+        F.img1C4 = c->d_img1C4 + G.src_off[s]; F.img1R4 = c->d_img1R4 + G.src_off[s]; F.mu1R4 = c->d_mu1R4 + G.src_off[s]; F.s11R4 = c->d_s11R4 + G.src_off[s];
+        F.work = c->d_work; F.part = c->d_part;
+        return F;
+    };
     for (int s = 0; s < G.nscales; s++) {
-        HParams Hp{}; Hp.G = G; Hp.K = c->K; Hp.s = s; Hp.npairs = npairs; Hp.ncol = c->ncol; Hp.perceptual = c->perceptual ? 1 : 0; Hp.use_maps = use_maps ? 1 : 0; Hp.sub_size = (int)c->sub_size;
-        Hp.packT = c->d_packT; Hp.pal_xyb = c->d_pal_xyb; Hp.cand_tab = c->d_cand_tab; Hp.cand_lab = c->d_cand_lab; Hp.labpxT = c->d_labpxT;
-        Hp.in1T = c->d_img1T + G.src_off[s]; Hp.in2T = nullptr; Hp.work = c->d_work; Hp.mapsT = c->d_mapsT; Hp.tile_pal = c->d_tile_pal;
-        int ppw = 256 / G.sh[s];
-        dim3 grid((npairs + ppw - 1) / ppw);
-        if (s == 0) {
-            if (c->timing) HIPCHK(hipEventRecord(tr.ev[1], c->stream));
-            if (c->perceptual && !use_maps) hipLaunchKernelGGL((k_hpass<true, true>), grid, dim3(256), 0, c->stream, Hp);
-            else hipLaunchKernelGGL((k_hpass<true, false>), grid, dim3(256), 0, c->stream, Hp);
-            if (c->timing) HIPCHK(hipEventRecord(tr.ev[2], c->stream));
-        } else hipLaunchKernelGGL((k_hpass<false, false>), grid, dim3(256), 0, c->stream, Hp);
+        if (s == 0 && c->timing) HIPCHK(hipEventRecord(tr.ev[1], c->stream));
+        if (is_fast(s)) {
+            FastParams F = fast_params(s);
+            dim3 grid((unsigned)(npairs * (G.sh[s] / 64)));
+            if (s == 0) hipLaunchKernelGGL((k_hpass_fast<true>), grid, dim3(64), 0, c->stream, F);
+            else hipLaunchKernelGGL((k_hpass_fast<false>), grid, dim3(64), 0, c->stream, F);
+        } else {
+            HParams Hp{}; Hp.G = G; Hp.K = c->K; Hp.s = s; Hp.npairs = npairs; Hp.ncol = c->ncol; Hp.perceptual = c->perceptual ? 1 : 0; Hp.use_maps = use_maps ? 1 : 0; Hp.sub_size = (int)c->sub_size;
+            Hp.packT = c->d_packT; Hp.pal_xyb = c->d_pal_xyb; Hp.cand_tab = c->d_cand_tab; Hp.cand_lab = c->d_cand_lab; Hp.labpxT = c->d_labpxT;
+            Hp.in1T = c->d_img1T + G.src_off[s]; Hp.in2T = nullptr; Hp.work = c->d_work; Hp.mapsT = c->d_mapsT; Hp.tile_pal = c->d_tile_pal;
+            int ppw = 256 / G.sh[s];
+            dim3 grid((npairs + ppw - 1) / ppw);
+            if (s == 0) {
+                if (c->perceptual && !use_maps) hipLaunchKernelGGL((k_hpass<true, true>), grid, dim3(256), 0, c->stream, Hp);
+                else hipLaunchKernelGGL((k_hpass<true, false>), grid, dim3(256), 0, c->stream, Hp);
+            } else hipLaunchKernelGGL((k_hpass<false, false>), grid, dim3(256), 0, c->stream, Hp);
+        }
+        if (s == 0 && c->timing) HIPCHK(hipEventRecord(tr.ev[2], c->stream));
     }
     for (int s = 0; s < G.nscales; s++) {
-        VParams Vp{}; Vp.G = G; Vp.K = c->K; Vp.s = s; Vp.npairs = npairs; Vp.ncol = c->ncol; Vp.perceptual = c->perceptual ? 1 : 0; Vp.use_maps = use_maps ? 1 : 0; Vp.sub_size = (int)c->sub_size;
-        Vp.pack = c->d_pack; Vp.pal_xyb = c->d_pal_xyb; Vp.cand_tab = c->d_cand_tab; Vp.cand_lab = c->d_cand_lab; Vp.labpx = c->d_labpx;
-        Vp.img1 = c->d_img1 + G.src_off[s]; Vp.mu1 = c->d_mu1 + G.src_off[s]; Vp.s11 = c->d_s11 + G.src_off[s]; Vp.work = c->d_work; Vp.part = c->d_part;
-        Vp.maps = c->d_maps; Vp.tile_pal = c->d_tile_pal;
+        if (s == 0 && c->timing) HIPCHK(hipEventRecord(tr.ev[3], c->stream));
         int ppv = 256 / G.sw[s];
         dim3 grid((npairs + ppv - 1) / ppv);
-        if (s == 0) {
-            if (c->timing) HIPCHK(hipEventRecord(tr.ev[3], c->stream));
-            if (c->perceptual && !use_maps) hipLaunchKernelGGL((k_vpass<true, false, true>), grid, dim3(256), 0, c->stream, Vp);
-            else hipLaunchKernelGGL((k_vpass<true, false, false>), grid, dim3(256), 0, c->stream, Vp);
-            if (c->timing) HIPCHK(hipEventRecord(tr.ev[4], c->stream));
-        } else hipLaunchKernelGGL((k_vpass<false, false, false>), grid, dim3(256), 0, c->stream, Vp);
+        if (is_fast(s)) {
+            FastParams F = fast_params(s);
+            if (s == 0) hipLaunchKernelGGL((k_vpass_fast<true>), grid, dim3(256), 0, c->stream, F);
+            else hipLaunchKernelGGL((k_vpass_fast<false>), grid, dim3(256), 0, c->stream, F);
+        } else {
+            VParams Vp{}; Vp.G = G; Vp.K = c->K; Vp.s = s; Vp.npairs = npairs; Vp.ncol = c->ncol; Vp.perceptual = c->perceptual ? 1 : 0; Vp.use_maps = use_maps ? 1 : 0; Vp.sub_size = (int)c->sub_size;
+            Vp.pack = c->d_pack; Vp.pal_xyb = c->d_pal_xyb; Vp.cand_tab = c->d_cand_tab; Vp.cand_lab = c->d_cand_lab; Vp.labpx = c->d_labpx;
+            Vp.img1 = c->d_img1 + G.src_off[s]; Vp.mu1 = c->d_mu1 + G.src_off[s]; Vp.s11 = c->d_s11 + G.src_off[s]; Vp.work = c->d_work; Vp.part = c->d_part;
+            Vp.maps = c->d_maps; Vp.tile_pal = c->d_tile_pal;
+            if (s == 0) {
+                if (c->perceptual && !use_maps) hipLaunchKernelGGL((k_vpass<true, false, true>), grid, dim3(256), 0, c->stream, Vp);
+                else hipLaunchKernelGGL((k_vpass<true, false, false>), grid, dim3(256), 0, c->stream, Vp);
+            } else hipLaunchKernelGGL((k_vpass<false, false, false>), grid, dim3(256), 0, c->stream, Vp);
+        }
+        if (s == 0 && c->timing) HIPCHK(hipEventRecord(tr.ev[4], c->stream));
     }
     hipLaunchKernelGGL(k_final_score, dim3((nc + 63) / 64), dim3(64), 0, c->stream, c->d_part, (int)nc, G, d_errors, err_stride, err_offset);
     HIPCHK(hipGetLastError());
@@ -422,6 +454,8 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
         G.off_hout[s] = off; off += 9 * N;
     }
     G.cand_stride = off;
+    for (int s = 0; s < G.nscales; s++) if ((G.sw[s] % 64) == 0 && (G.sh[s] % 64) == 0) c->fast_mask |= 1 << s;
+    if (const char *e = getenv("SNES_NO_FAST")) { if (atoi(e)) c->fast_mask = 0; }
     c->src_floats = (size_t)soff;
 
     int32_t rc = SNES_OK;
@@ -434,6 +468,8 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
         HIPCHK(hipMalloc(&c->d_map, c->npx));
         HIPCHK(hipMalloc(&c->d_pack, c->npx * 8));
         HIPCHK(hipMalloc(&c->d_packT, c->npx * 8));
+        HIPCHK(hipMalloc(&c->d_packC4, c->npx * 8));
+        HIPCHK(hipMalloc(&c->d_packR4, c->npx * 8));
         HIPCHK(hipMalloc(&c->d_eotf, 256 * 4));
         HIPCHK(hipMalloc(&c->d_lab_eotf, 256 * 4));
         HIPCHK(hipMalloc(&c->d_pal_rgb8, 256 * 4));
@@ -445,6 +481,10 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
         HIPCHK(hipMalloc(&c->d_img1T, c->src_floats * 4));
         HIPCHK(hipMalloc(&c->d_mu1, c->src_floats * 4));
         HIPCHK(hipMalloc(&c->d_s11, c->src_floats * 4));
+        HIPCHK(hipMalloc(&c->d_img1C4, c->src_floats * 4));
+        HIPCHK(hipMalloc(&c->d_img1R4, c->src_floats * 4));
+        HIPCHK(hipMalloc(&c->d_mu1R4, c->src_floats * 4));
+        HIPCHK(hipMalloc(&c->d_s11R4, c->src_floats * 4));
         if (c->perceptual) { HIPCHK(hipMalloc(&c->d_labpx, c->npx * 3 * 4)); HIPCHK(hipMalloc(&c->d_labpxT, c->npx * 3 * 4)); }
         HIPCHK(hipMalloc(&c->d_inc_err, sizeof(double)));
         HIPCHK(hipMalloc(&c->d_scratch_err, sizeof(double)));
@@ -475,6 +515,7 @@ void snesimage_destroy(snesimage_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)drain_timing(c);
+    dfree(c->d_packC4); dfree(c->d_packR4); dfree(c->d_img1C4); dfree(c->d_img1R4); dfree(c->d_mu1R4); dfree(c->d_s11R4);
     dfree(c->d_orig); dfree(c->d_tile_pal); dfree(c->d_colors); dfree(c->d_map); dfree(c->d_pack); dfree(c->d_packT); dfree(c->d_eotf); dfree(c->d_lab_eotf);
     dfree(c->d_pal_rgb8); dfree(c->d_pal_lin); dfree(c->d_pal_xyb); dfree(c->d_pal_lab); dfree(c->d_lin0); dfree(c->d_img1); dfree(c->d_img1T); dfree(c->d_mu1); dfree(c->d_s11);
     dfree(c->d_labpx); dfree(c->d_labpxT); dfree(c->d_work); dfree(c->d_cand_tab); dfree(c->d_cand_lab); dfree(c->d_part); dfree(c->d_maps); dfree(c->d_mapsT);

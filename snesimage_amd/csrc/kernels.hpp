@@ -24,6 +24,11 @@ namespace snes {
 constexpr int kMaxScales = 6;
 constexpr int kBlurRadius = 5; // N of ssimulacra2's recursive Gaussian at sigma = 1.5
 
+// Blocked layouts used by the wide-access kernels of kernels_fast.hpp
+SNES_HD long long idx_c4(int x, int y, int H) { return ((long long)(x >> 2) * H + y) * 4 + (x & 3); }   // [x/4][y][x%4]
+SNES_HD long long idx_r4(int x, int y, int W) { return ((long long)(y >> 2) * W + x) * 4 + (y & 3); }   // [y/4][x][y%4]
+SNES_HD long long idx_xt4(int x, int y, int H) { return ((((long long)(x >> 6) * (H >> 2)) + (y >> 2)) << 8) + ((x & 63) << 2) + (y & 3); } // [x/64][y/4][x%64][y%4]
+
 struct BlurK { // recursive-Gaussian constants (host-computed in binary64, rounded to f32)
     float n2[3];   // MUL_IN_k = VERT_MUL_IN_k
     float d1[3];   // VERT_MUL_PREV_k; MUL_PREV_k = -d1
@@ -99,7 +104,7 @@ __global__ void k_candidate_tables(const uint8_t *__restrict__ rgb5, int n, cons
 // ------------------------------------------------------------------------------------------------
 struct PrepParams {
     const uint8_t *orig; const uint8_t *tile_pal; const uint32_t *pal_rgb8; uint8_t *map;
-    unsigned long long *pack, *packT;
+    unsigned long long *pack, *packT, *packC4, *packR4;
     const float *labpx; const float *pal_lab; // perceptual only
     int W, H, sub_size, ncol, mode, sp, si, perceptual;
 };
@@ -156,6 +161,8 @@ __global__ __launch_bounds__(256) void k_prep(PrepParams P) {
     unsigned long long w = (unsigned long long)(rgb | (ci << 24)) | ((unsigned long long)thr << 32);
     P.pack[px] = w;
     P.packT[(size_t)x * P.H + y] = w;
+    P.packC4[idx_c4(x, y, P.H)] = w;
+    P.packR4[idx_r4(x, y, P.W)] = w;
 }
 
 // Which colour index does pixel `pk` take for a candidate with 8-bit colour crgb / Lab clab?
@@ -214,7 +221,7 @@ struct DownParams {
     const float *lin0; // CAND=false
     float *work;       // candidate workspace base (CAND) or source img1 base (!CAND)
     float *workT;      // !CAND: source img1T base
-    int ncol, perceptual, use_maps;
+    int ncol, perceptual, use_maps, fast_mask; // fast_mask bit s: scale s planes are stored R4 (off_xyb) and C4 (off_xybT)
     const uint8_t *maps; const uint8_t *tile_pal; int sub_size; // use_maps: ci from per-candidate maps (dither path)
 };
 
@@ -277,7 +284,8 @@ __global__ __launch_bounds__(256) void k_downscale_chain(DownParams P) {
         if (in) {
             size_t n1 = (size_t)W1 * H1;
             float *o = wbase + (CAND ? G.off_xyb[1] : G.src_off[1]);
-            o[(size_t)Y1 * W1 + X1] = X; o[n1 + (size_t)Y1 * W1 + X1] = Y; o[2 * n1 + (size_t)Y1 * W1 + X1] = B;
+            const size_t oi = (CAND && (P.fast_mask & 2)) ? (size_t)idx_r4(X1, Y1, W1) : (size_t)Y1 * W1 + X1;
+            o[oi] = X; o[n1 + oi] = Y; o[2 * n1 + oi] = B;
         }
         __syncthreads();
         // transposed copy: thread (tx = t>>4 -> x, ty = t&15 -> y) so y is the fast index
@@ -287,7 +295,8 @@ __global__ __launch_bounds__(256) void k_downscale_chain(DownParams P) {
             if (YT < H1) {
                 size_t n1 = (size_t)W1 * H1;
                 float *oT = CAND ? (wbase + G.off_xybT[1]) : (P.workT + G.src_off[1]);
-                oT[(size_t)XT * H1 + YT] = tr[0][ty][tx]; oT[n1 + (size_t)XT * H1 + YT] = tr[1][ty][tx]; oT[2 * n1 + (size_t)XT * H1 + YT] = tr[2][ty][tx];
+                const size_t ti = (CAND && (P.fast_mask & 2)) ? (size_t)idx_c4(XT, YT, H1) : (size_t)XT * H1 + YT;
+                oT[ti] = tr[0][ty][tx]; oT[n1 + ti] = tr[1][ty][tx]; oT[2 * n1 + ti] = tr[2][ty][tx];
             }
         }
     }
@@ -311,8 +320,11 @@ __global__ __launch_bounds__(256) void k_downscale_chain(DownParams P) {
                 size_t ns = (size_t)WS * HS;                                                                                  \
                 float *o = wbase + (CAND ? G.off_xyb[S] : G.src_off[S]);                                                      \
                 float *oT = CAND ? (wbase + G.off_xybT[S]) : (P.workT + G.src_off[S]);                                        \
-                o[(size_t)YS * WS + XS] = X; o[ns + (size_t)YS * WS + XS] = Y; o[2 * ns + (size_t)YS * WS + XS] = B;          \
-                oT[(size_t)XS * HS + YS] = X; oT[ns + (size_t)XS * HS + YS] = Y; oT[2 * ns + (size_t)XS * HS + YS] = B;       \
+                const bool fst = CAND && ((P.fast_mask >> S) & 1);                                                            \
+                const size_t oi = fst ? (size_t)idx_r4(XS, YS, WS) : (size_t)YS * WS + XS;                                    \
+                const size_t ti = fst ? (size_t)idx_c4(XS, YS, HS) : (size_t)XS * HS + YS;                                    \
+                o[oi] = X; o[ns + oi] = Y; o[2 * ns + oi] = B;                                                                \
+                oT[ti] = X; oT[ns + ti] = Y; oT[2 * ns + ti] = B;                                                             \
             }                                                                                                                 \
         }                                                                                                                     \
         __syncthreads();                                                                                                      \
