@@ -12,7 +12,9 @@
 //     ([x/64][y/4][x%64][y%4]), written after a 4x4 transpose through a 3.75 KiB per-wave LDS pad;
 //   * loads for the next group of four steps are issued before the current group is computed
 //     (software prefetch), so a step never waits on HBM/L2 latency;
-//   * the 10-deep delay line of the truncated-cosine filter (in[n-6]) is a 3-group register ring.
+//   * the 10-deep delay line of the truncated-cosine filter (in[n-6]) is a five-slot register ring that the
+//     prefetch loads write directly; the recurrence state alternates between two register sets instead of
+//     being shifted, so the inner loop moves no registers.
 #pragma once
 #include "kernels.hpp"
 
@@ -28,17 +30,38 @@ struct FastParams {
     float *work; double *part;
 };
 
-// colour index of 4 pixels from their pack words (RGB / redmean keys)
+// colour index of 4 pixels from their pack words (RGB / redmean keys).  thr == 0 ("candidate never wins")
+// needs no special case: an unsigned key is never < 0.
 __device__ __forceinline__ void resolve4(const uint4 a, const uint4 b, uint32_t crgb, uint32_t ncol, uint32_t ci[4]) {
     const uint32_t lo[4] = {a.x, a.z, b.x, b.z}, hi[4] = {a.y, a.w, b.y, b.w};
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint32_t ci0 = lo[j] >> 24;
-        ci[j] = (hi[j] != 0u && red_mean_key(crgb, lo[j] & 0x00ffffffu) < hi[j]) ? ncol : ci0;
-    }
+    for (int j = 0; j < 4; j++) ci[j] = red_mean_key(crgb, lo[j] & 0x00ffffffu) < hi[j] ? ncol : (lo[j] >> 24);
 }
 
+// One step of the three recurrences of a plane.  A holds y[n-1], B holds y[n-2]; the new value is written
+// over B, so the caller swaps the roles of A and B on the next step instead of moving registers.
+// Horizontal form (blur/gaussian.rs horizontal_row): out = fma(MUL_PREV, prev, fma(-1, prev2, sum * MUL_IN))
+#define SNES_HSTEP(SUM, A, B, OUT)                                                   \
+    {                                                                                \
+        float o1_ = (SUM) * n2_0, o3_ = (SUM) * n2_1, o5_ = (SUM) * n2_2;            \
+        o1_ = fmaf(-1.0f, B[0], o1_); o3_ = fmaf(-1.0f, B[1], o3_); o5_ = fmaf(-1.0f, B[2], o5_); \
+        o1_ = fmaf(mp_0, A[0], o1_); o3_ = fmaf(mp_1, A[1], o3_); o5_ = fmaf(mp_2, A[2], o5_);    \
+        B[0] = o1_; B[1] = o3_; B[2] = o5_;                                          \
+        OUT = o1_ + o3_ + o5_;                                                       \
+    }
+// Vertical form (vertical_pass): out = fma(sum, MUL_IN, -fma(prev, MUL_PREV, prev2))
+#define SNES_VSTEP(SUM, A, B, OUT)                                                   \
+    {                                                                                \
+        float o1_ = fmaf(A[0], d1_0, B[0]), o3_ = fmaf(A[1], d1_1, B[1]), o5_ = fmaf(A[2], d1_2, B[2]); \
+        o1_ = fmaf((SUM), n2_0, -o1_); o3_ = fmaf((SUM), n2_1, -o3_); o5_ = fmaf((SUM), n2_2, -o5_);    \
+        B[0] = o1_; B[1] = o3_; B[2] = o5_;                                          \
+        OUT = o1_ + o3_ + o5_;                                                       \
+    }
+
 // ---- H pass: one wave = rows [64*yb, 64*yb+64) of one (candidate, channel) -------------------------
+// Groups of four columns; group g carries the "right" inputs in[4g..4g+3] of steps n = 4g-4..4g-1.  A
+// five-slot register ring holds groups g-3..g+1: g+1 is the prefetch target (loads land in the ring,
+// nothing is copied), g-3 and g-2 supply in[n-6].
 template <bool S0>
 __global__ __launch_bounds__(64) void k_hpass_fast(FastParams P) {
     __shared__ float s_lut[256];
@@ -59,82 +82,74 @@ __global__ __launch_bounds__(64) void k_hpass_fast(FastParams P) {
         crgb = __float_as_uint(P.cand_tab[8 * (size_t)cand + 6]);
         __syncthreads();
     }
-    const float4 *in1 = reinterpret_cast<const float4 *>(P.img1C4 + (size_t)ch * ns) + y;        // + g*H
+    const float4 *in1 = reinterpret_cast<const float4 *>(P.img1C4 + (size_t)ch * ns) + y;                                   // advances by H per group
     const float4 *in2 = S0 ? nullptr : reinterpret_cast<const float4 *>(P.work + (size_t)cand * G.cand_stride + G.off_xybT[s] + (size_t)ch * ns) + y;
-    const uint4 *pk = S0 ? reinterpret_cast<const uint4 *>(P.packC4) + 2 * (size_t)y : nullptr;     // + g*H*2
+    const uint4 *pk = S0 ? reinterpret_cast<const uint4 *>(P.packC4) + 2 * (size_t)y : nullptr;                              // advances by 2H per group
     float *hout = P.work + (size_t)cand * G.cand_stride + G.off_hout[s] + (size_t)(ch * 3) * ns;
+    // XT4 offset of (x = 4(g-1) + (lane&3), y = 64*yb + (lane&~3)); per group x advances by 4 -> +16 floats, and by a whole
+    // column block (H*64 floats) every 16 groups
+    const int li = lane & 3, k4 = lane & ~3;
+    const size_t o_row = ((size_t)(((yb << 6) + k4) >> 2) << 8) + ((size_t)li << 2);
 
     const float n2_0 = P.K.n2[0], n2_1 = P.K.n2[1], n2_2 = P.K.n2[2];
     const float mp_0 = -P.K.d1[0], mp_1 = -P.K.d1[1], mp_2 = -P.K.d1[2];
-    float pv[3][3], pv2[3][3];
+    float sa[3][3], sb[3][3]; // recurrence state per plane: roles (prev, prev2) alternate every step
 #pragma unroll
     for (int p = 0; p < 3; p++)
 #pragma unroll
-        for (int k = 0; k < 3; k++) { pv[p][k] = 0.0f; pv2[p][k] = 0.0f; }
-    float r1[4][4], r2[4][4]; // ring of the last four groups: [slot][element]
+        for (int k = 0; k < 3; k++) { sa[p][k] = 0.0f; sb[p][k] = 0.0f; }
+    float4 r1[5], r2[5];
 #pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) { r1[a][b] = 0.0f; r2[a][b] = 0.0f; }
+    for (int a = 0; a < 5; a++) { r1[a] = make_float4(0.f, 0.f, 0.f, 0.f); r2[a] = r1[a]; }
 
     const int G4 = W >> 2;
-    float4 n_v1 = in1[0];
-    float4 n_v2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint4 n_pa = make_uint4(0, 0, 0, 0), n_pb = make_uint4(0, 0, 0, 0);
-    if (S0) { n_pa = pk[0]; n_pb = pk[1]; } else n_v2 = in2[0];
+    uint4 n_pa = make_uint4(0, 0, 0, 0), n_pb = n_pa;
+    r1[0] = in1[0];
+    if (S0) { n_pa = pk[0]; n_pb = pk[1]; } else r2[0] = in2[0];
+    in1 += H; if (S0) pk += 2 * (size_t)H; else in2 += H;
 
-    for (int g0 = 0; g0 <= G4; g0 += 4) {
+    for (int g0 = 0; g0 <= G4; g0 += 5) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < 5; u++) {
             const int g = g0 + u;
             if (g > G4) break;
-            // take the prefetched group, issue the next group's loads
-            const float4 c_v1 = n_v1; float4 c_v2 = n_v2; const uint4 c_pa = n_pa, c_pb = n_pb;
-            if (g + 1 < G4) {
-                n_v1 = in1[(size_t)(g + 1) * H];
-                if (S0) { n_pa = pk[(size_t)(g + 1) * H * 2]; n_pb = pk[(size_t)(g + 1) * H * 2 + 1]; } else n_v2 = in2[(size_t)(g + 1) * H];
-            } else { n_v1 = make_float4(0.f, 0.f, 0.f, 0.f); n_v2 = n_v1; n_pa = make_uint4(0, 0, 0, 0); n_pb = n_pa; }
-            float v1[4] = {c_v1.x, c_v1.y, c_v1.z, c_v1.w};
-            float v2[4];
-            if (g >= G4) { v1[0] = v1[1] = v1[2] = v1[3] = 0.0f; v2[0] = v2[1] = v2[2] = v2[3] = 0.0f; }
-            else if (S0) {
+            const int un = (u + 1) % 5, ua = (u + 2) % 5, ub = (u + 3) % 5; // slots of groups g+1, g-3, g-2
+            const uint4 c_pa = n_pa, c_pb = n_pb;
+            if (g + 1 < G4) { // prefetch group g+1 straight into its ring slot
+                r1[un] = in1[0]; in1 += H;
+                if (S0) { n_pa = pk[0]; n_pb = pk[1]; pk += 2 * (size_t)H; } else { r2[un] = in2[0]; in2 += H; }
+            } else { r1[un] = make_float4(0.f, 0.f, 0.f, 0.f); r2[un] = r1[un]; n_pa = make_uint4(0, 0, 0, 0); n_pb = n_pa; }
+            if (S0 && g < G4) {
                 uint32_t ci[4];
                 resolve4(c_pa, c_pb, crgb, (uint32_t)P.ncol, ci);
-#pragma unroll
-                for (int j = 0; j < 4; j++) v2[j] = (ci[j] == (uint32_t)P.ncol) ? cand_v : s_lut[ci[j]];
-            } else { v2[0] = c_v2.x; v2[1] = c_v2.y; v2[2] = c_v2.z; v2[3] = c_v2.w; }
-#pragma unroll
-            for (int j = 0; j < 4; j++) { r1[u][j] = v1[j]; r2[u][j] = v2[j]; }
+                r2[u].x = (ci[0] == (uint32_t)P.ncol) ? cand_v : s_lut[ci[0]];
+                r2[u].y = (ci[1] == (uint32_t)P.ncol) ? cand_v : s_lut[ci[1]];
+                r2[u].z = (ci[2] == (uint32_t)P.ncol) ? cand_v : s_lut[ci[2]];
+                r2[u].w = (ci[3] == (uint32_t)P.ncol) ? cand_v : s_lut[ci[3]];
+            }
+            const float v1[4] = {r1[u].x, r1[u].y, r1[u].z, r1[u].w}, v2[4] = {r2[u].x, r2[u].y, r2[u].z, r2[u].w};
+            const float l1[4] = {r1[ua].z, r1[ua].w, r1[ub].x, r1[ub].y}, l2[4] = {r2[ua].z, r2[ua].w, r2[ub].x, r2[ub].y}; // in[xr - 10]
             float outp[3][4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                // in[xr - 10]: group g-3 (slot u+1) elements 2,3 for j = 0,1; group g-2 (slot u+2) elements 0,1 for j = 2,3
-                const float l1v = j < 2 ? r1[(u + 1) & 3][j + 2] : r1[(u + 2) & 3][j - 2];
-                const float l2v = j < 2 ? r2[(u + 1) & 3][j + 2] : r2[(u + 2) & 3][j - 2];
-                const float sums[3] = {l2v + v2[j], (l2v * l2v) + (v2[j] * v2[j]), (l1v * l2v) + (v1[j] * v2[j])};
+                const float s0 = l2[j] + v2[j];
+                const float s1 = (l2[j] * l2[j]) + (v2[j] * v2[j]);
+                const float s2 = (l1[j] * l2[j]) + (v1[j] * v2[j]);
+                if ((j & 1) == 0) { SNES_HSTEP(s0, sa[0], sb[0], outp[0][j]) SNES_HSTEP(s1, sa[1], sb[1], outp[1][j]) SNES_HSTEP(s2, sa[2], sb[2], outp[2][j]) }
+                else { SNES_HSTEP(s0, sb[0], sa[0], outp[0][j]) SNES_HSTEP(s1, sb[1], sa[1], outp[1][j]) SNES_HSTEP(s2, sb[2], sa[2], outp[2][j]) }
+            }
+            if (g >= 1) { // outputs x = 4(g-1)..4(g-1)+3 of row y: 4x4 transpose inside each lane quad, then one 16-byte store per plane
 #pragma unroll
                 for (int p = 0; p < 3; p++) {
-                    float o1 = sums[p] * n2_0, o3 = sums[p] * n2_1, o5 = sums[p] * n2_2;
-                    o1 = fmaf(-1.0f, pv2[p][0], o1); o3 = fmaf(-1.0f, pv2[p][1], o3); o5 = fmaf(-1.0f, pv2[p][2], o5);
-                    pv2[p][0] = pv[p][0]; pv2[p][1] = pv[p][1]; pv2[p][2] = pv[p][2];
-                    o1 = fmaf(mp_0, pv[p][0], o1); o3 = fmaf(mp_1, pv[p][1], o3); o5 = fmaf(mp_2, pv[p][2], o5);
-                    pv[p][0] = o1; pv[p][1] = o3; pv[p][2] = o5;
-                    outp[p][j] = o1 + o3 + o5;
+                    s_tr[p][lane * 5 + 0] = outp[p][0]; s_tr[p][lane * 5 + 1] = outp[p][1]; s_tr[p][lane * 5 + 2] = outp[p][2]; s_tr[p][lane * 5 + 3] = outp[p][3];
                 }
-            }
-            if (g >= 1) { // outputs x = 4(g-1) .. 4(g-1)+3 of row y: transpose 4x4 across each lane quad, store XT4
-#pragma unroll
-                for (int p = 0; p < 3; p++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) s_tr[p][lane * 5 + j] = outp[p][j];
                 __syncthreads();
-                const int i = lane & 3, k4 = lane & ~3;
-                const int x = ((g - 1) << 2) + i;
-                const size_t o = (size_t)idx_xt4(x, (yb << 6) + k4, H);
+                const int xg = (g - 1) << 2; // first column of the group
+                const size_t o = (((size_t)(xg >> 6) * (size_t)(H >> 2)) << 8) + o_row + ((size_t)(xg & 63) << 2);
 #pragma unroll
                 for (int p = 0; p < 3; p++) {
                     float4 v;
-                    v.x = s_tr[p][(k4 + 0) * 5 + i]; v.y = s_tr[p][(k4 + 1) * 5 + i]; v.z = s_tr[p][(k4 + 2) * 5 + i]; v.w = s_tr[p][(k4 + 3) * 5 + i];
+                    v.x = s_tr[p][(k4 + 0) * 5 + li]; v.y = s_tr[p][(k4 + 1) * 5 + li]; v.z = s_tr[p][(k4 + 2) * 5 + li]; v.w = s_tr[p][(k4 + 3) * 5 + li];
                     *reinterpret_cast<float4 *>(hout + (size_t)p * ns + o) = v;
                 }
                 __syncthreads();
@@ -166,92 +181,75 @@ __global__ __launch_bounds__(256) void k_vpass_fast(FastParams P) {
         crgb = __float_as_uint(P.cand_tab[8 * (size_t)cand + 6]);
         __syncthreads();
     }
+    const float *lut = s_lut[ch];
     const int H4 = H >> 2;
-    // XT4: float4 index ((xb*H4 + g) << 6) + lane
-    const float4 *hout = reinterpret_cast<const float4 *>(P.work + (size_t)cand * G.cand_stride + G.off_hout[s] + (size_t)(ch * 3) * ns) + (((size_t)(x >> 6) * H4) << 6) + (x & 63);
     const size_t plane4 = ns >> 2;
-    // R4: float4 index g*W + x
+    // XT4: float4 index ((xb*H4 + g) << 6) + lane; advances by 64 per row group
+    const float4 *h0 = reinterpret_cast<const float4 *>(P.work + (size_t)cand * G.cand_stride + G.off_hout[s] + (size_t)(ch * 3) * ns) + (((size_t)(x >> 6) * H4) << 6) + (x & 63);
+    const float4 *h1 = h0 + plane4, *h2 = h1 + plane4;
+    // R4: float4 index g*W + x; advances by W per row group
     const float4 *img1 = reinterpret_cast<const float4 *>(P.img1R4 + (size_t)ch * ns) + x;
     const float4 *mu1 = reinterpret_cast<const float4 *>(P.mu1R4 + (size_t)ch * ns) + x;
     const float4 *s11 = reinterpret_cast<const float4 *>(P.s11R4 + (size_t)ch * ns) + x;
     const float4 *xyb = S0 ? nullptr : reinterpret_cast<const float4 *>(P.work + (size_t)cand * G.cand_stride + G.off_xyb[s] + (size_t)ch * ns) + x;
-    const uint4 *pk = S0 ? reinterpret_cast<const uint4 *>(P.packR4) + 2 * (size_t)x : nullptr; // + g*W*2
+    const uint4 *pk = S0 ? reinterpret_cast<const uint4 *>(P.packR4) + 2 * (size_t)x : nullptr;
 
     const float n2_0 = P.K.n2[0], n2_1 = P.K.n2[1], n2_2 = P.K.n2[2];
     const float d1_0 = P.K.d1[0], d1_1 = P.K.d1[1], d1_2 = P.K.d1[2];
-    float pv[3][3], pv2[3][3];
+    float sa[3][3], sb[3][3];
 #pragma unroll
     for (int p = 0; p < 3; p++)
 #pragma unroll
-        for (int k = 0; k < 3; k++) { pv[p][k] = 0.0f; pv2[p][k] = 0.0f; }
-    float ring[3][4][4]; // [plane][slot][element]
+        for (int k = 0; k < 3; k++) { sa[p][k] = 0.0f; sb[p][k] = 0.0f; }
+    float4 ring[3][5];
 #pragma unroll
     for (int p = 0; p < 3; p++)
 #pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) ring[p][a][b] = 0.0f;
+        for (int a = 0; a < 5; a++) ring[p][a] = make_float4(0.f, 0.f, 0.f, 0.f);
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
-    float4 n_h[3];
-#pragma unroll
-    for (int p = 0; p < 3; p++) n_h[p] = hout[(size_t)p * plane4];
-    // map inputs of row group g-1 are fetched one group ahead as well
+    ring[0][0] = __builtin_nontemporal_load(h0); ring[1][0] = __builtin_nontemporal_load(h1); ring[2][0] = __builtin_nontemporal_load(h2);
+    h0 += 64; h1 += 64; h2 += 64;
+    // map inputs of row group g-1 travel one iteration ahead of their use
     float4 n_i1 = make_float4(0.f, 0.f, 0.f, 0.f), n_m1 = n_i1, n_s11 = n_i1, n_x = n_i1;
     uint4 n_pa = make_uint4(0, 0, 0, 0), n_pb = n_pa;
 
-    for (int g0 = 0; g0 <= H4; g0 += 4) {
+    for (int g0 = 0; g0 <= H4; g0 += 5) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < 5; u++) {
             const int g = g0 + u;
             if (g > H4) break;
-            float4 c_h[3];
-#pragma unroll
-            for (int p = 0; p < 3; p++) c_h[p] = n_h[p];
+            const int un = (u + 1) % 5, ua = (u + 2) % 5, ub = (u + 3) % 5;
             const float4 c_i1 = n_i1, c_m1 = n_m1, c_s11 = n_s11, c_x = n_x; const uint4 c_pa = n_pa, c_pb = n_pb;
-            if (g + 1 < H4) {
-#pragma unroll
-                for (int p = 0; p < 3; p++) n_h[p] = hout[(size_t)p * plane4 + ((size_t)(g + 1) << 6)];
-            } else {
-#pragma unroll
-                for (int p = 0; p < 3; p++) n_h[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            if (g + 1 < H4) { ring[0][un] = __builtin_nontemporal_load(h0); ring[1][un] = __builtin_nontemporal_load(h1); ring[2][un] = __builtin_nontemporal_load(h2); h0 += 64; h1 += 64; h2 += 64; }
+            else { ring[0][un] = make_float4(0.f, 0.f, 0.f, 0.f); ring[1][un] = ring[0][un]; ring[2][un] = ring[0][un]; }
             if (g < H4) { // inputs of the maps of rows 4g..4g+3, consumed in the next iteration
-                n_i1 = img1[(size_t)g * W]; n_m1 = mu1[(size_t)g * W]; n_s11 = s11[(size_t)g * W];
-                if (S0) { n_pa = pk[(size_t)g * W * 2]; n_pb = pk[(size_t)g * W * 2 + 1]; } else n_x = xyb[(size_t)g * W];
-            }
-            float in[3][4];
-#pragma unroll
-            for (int p = 0; p < 3; p++) {
-                if (g >= H4) { in[p][0] = in[p][1] = in[p][2] = in[p][3] = 0.0f; }
-                else { in[p][0] = c_h[p].x; in[p][1] = c_h[p].y; in[p][2] = c_h[p].z; in[p][3] = c_h[p].w; }
-#pragma unroll
-                for (int j = 0; j < 4; j++) ring[p][u][j] = in[p][j];
+                n_i1 = img1[0]; n_m1 = mu1[0]; n_s11 = s11[0]; img1 += W; mu1 += W; s11 += W;
+                if (S0) { n_pa = pk[0]; n_pb = pk[1]; pk += 2 * (size_t)W; } else { n_x = xyb[0]; xyb += W; }
             }
             float i2v[4] = {c_x.x, c_x.y, c_x.z, c_x.w};
             if (S0 && g >= 1) {
                 uint32_t ci[4];
                 resolve4(c_pa, c_pb, crgb, (uint32_t)P.ncol, ci);
 #pragma unroll
-                for (int j = 0; j < 4; j++) i2v[j] = (ci[j] == (uint32_t)P.ncol) ? cand_v : s_lut[ch][ci[j]];
+                for (int j = 0; j < 4; j++) i2v[j] = (ci[j] == (uint32_t)P.ncol) ? cand_v : lut[ci[j]];
             }
             const float i1v[4] = {c_i1.x, c_i1.y, c_i1.z, c_i1.w}, m1v[4] = {c_m1.x, c_m1.y, c_m1.z, c_m1.w}, s11v[4] = {c_s11.x, c_s11.y, c_s11.z, c_s11.w};
+            float in[3][4], top[3][4];
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+                in[p][0] = ring[p][u].x; in[p][1] = ring[p][u].y; in[p][2] = ring[p][u].z; in[p][3] = ring[p][u].w;
+                top[p][0] = ring[p][ua].z; top[p][1] = ring[p][ua].w; top[p][2] = ring[p][ub].x; top[p][3] = ring[p][ub].y; // hout[n - 6]
+            }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 float outp[3];
-#pragma unroll
-                for (int p = 0; p < 3; p++) {
-                    const float top = j < 2 ? ring[p][(u + 1) & 3][j + 2] : ring[p][(u + 2) & 3][j - 2];
-                    const float sum = top + in[p][j];
-                    float o1 = fmaf(pv[p][0], d1_0, pv2[p][0]);
-                    float o3 = fmaf(pv[p][1], d1_1, pv2[p][1]);
-                    float o5 = fmaf(pv[p][2], d1_2, pv2[p][2]);
-                    o1 = fmaf(sum, n2_0, -o1); o3 = fmaf(sum, n2_1, -o3); o5 = fmaf(sum, n2_2, -o5);
-                    pv2[p][0] = pv[p][0]; pv2[p][1] = pv[p][1]; pv2[p][2] = pv[p][2];
-                    pv[p][0] = o1; pv[p][1] = o3; pv[p][2] = o5;
-                    outp[p] = o1 + o3 + o5;
+                if ((j & 1) == 0) {
+                    SNES_VSTEP(top[0][j] + in[0][j], sa[0], sb[0], outp[0]) SNES_VSTEP(top[1][j] + in[1][j], sa[1], sb[1], outp[1]) SNES_VSTEP(top[2][j] + in[2][j], sa[2], sb[2], outp[2])
+                } else {
+                    SNES_VSTEP(top[0][j] + in[0][j], sb[0], sa[0], outp[0]) SNES_VSTEP(top[1][j] + in[1][j], sb[1], sa[1], outp[1]) SNES_VSTEP(top[2][j] + in[2][j], sb[2], sa[2], outp[2])
                 }
-                if (g >= 1 && active) { // row n = 4(g-1) + j
+                if (g >= 1) { // row n = 4(g-1) + j: ssim_map and edge_diff_map terms
                     const float m1 = m1v[j], m2 = outp[0], v11 = s11v[j], v22 = outp[1], v12 = outp[2];
                     const float i1 = i1v[j], i2 = i2v[j];
                     const float mu11 = m1 * m1, mu22 = m2 * m2, mu12 = m1 * m2;
@@ -293,6 +291,8 @@ __global__ __launch_bounds__(256) void k_vpass_fast(FastParams P) {
         for (int k = 0; k < 6; k++) o[k] = red[t][k];
     }
 }
+#undef SNES_HSTEP
+#undef SNES_VSTEP
 
 // Row-major [3][H][W] source planes -> R4 and/or C4 copies (one-off, per context)
 __global__ __launch_bounds__(256) void k_relayout(const float *__restrict__ src, int W, int H, float *__restrict__ r4, float *__restrict__ c4) {
