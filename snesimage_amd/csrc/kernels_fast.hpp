@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_vpass_fast(FastParams P) {
         for (int a = 0; a < 5; a++) ring[p][a] = make_float4(0.f, 0.f, 0.f, 0.f);
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
-    ring[0][0] = __builtin_nontemporal_load(h0); ring[1][0] = __builtin_nontemporal_load(h1); ring[2][0] = __builtin_nontemporal_load(h2);
+    ring[0][0] = h0[0]; ring[1][0] = h1[0]; ring[2][0] = h2[0];
     h0 += 64; h1 += 64; h2 += 64;
     // map inputs of row group g-1 travel one iteration ahead of their use
     float4 n_i1 = make_float4(0.f, 0.f, 0.f, 0.f), n_m1 = n_i1, n_s11 = n_i1, n_x = n_i1;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k_vpass_fast(FastParams P) {
             if (g > H4) break;
             const int un = (u + 1) % 5, ua = (u + 2) % 5, ub = (u + 3) % 5;
             const float4 c_i1 = n_i1, c_m1 = n_m1, c_s11 = n_s11, c_x = n_x; const uint4 c_pa = n_pa, c_pb = n_pb;
-            if (g + 1 < H4) { ring[0][un] = __builtin_nontemporal_load(h0); ring[1][un] = __builtin_nontemporal_load(h1); ring[2][un] = __builtin_nontemporal_load(h2); h0 += 64; h1 += 64; h2 += 64; }
+            if (g + 1 < H4) { ring[0][un] = h0[0]; ring[1][un] = h1[0]; ring[2][un] = h2[0]; h0 += 64; h1 += 64; h2 += 64; }
             else { ring[0][un] = make_float4(0.f, 0.f, 0.f, 0.f); ring[1][un] = ring[0][un]; ring[2][un] = ring[0][un]; }
             if (g < H4) { // inputs of the maps of rows 4g..4g+3, consumed in the next iteration
                 n_i1 = img1[0]; n_m1 = mu1[0]; n_s11 = s11[0]; img1 += W; mu1 += W; s11 += W;
