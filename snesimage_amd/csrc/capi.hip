@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 using namespace snes;
@@ -94,7 +95,7 @@ struct snesimage_ctx {
     Geom G{};
     BlurK K{};
     size_t npx = 0, src_floats = 0;
-    uint32_t chunk = 256, chunk_alloc = 0;
+    uint32_t chunk = 512, chunk_alloc = 0;
 
     std::vector<uint8_t> h_orig; float h_eotf[256], h_lab_eotf[256];
 
@@ -111,6 +112,10 @@ struct snesimage_ctx {
     float *d_work = nullptr, *d_cand_tab = nullptr, *d_cand_lab = nullptr;
     double *d_part = nullptr;
     uint8_t *d_maps = nullptr, *d_mapsT = nullptr; // dither path: per-candidate maps
+    // Additional launch lanes: chunk i of a candidate list runs on lane i % nlanes (lane 0 = the context's stream and the
+    // workspace above), so the HBM-bound H pass of one chunk overlaps the VALU-bound V pass of another.
+    struct Lane { hipStream_t stream = nullptr; float *d_work = nullptr, *d_cand_tab = nullptr, *d_cand_lab = nullptr; double *d_part = nullptr; uint8_t *d_maps = nullptr, *d_mapsT = nullptr; hipEvent_t done = nullptr; };
+    std::vector<Lane> extra; uint32_t nlanes = 2; hipEvent_t ev_ready = nullptr;
     // step state
     uint8_t *d_cand = nullptr; uint32_t cand_cap = 0;
     uint8_t *d_cand_sel = nullptr;
@@ -137,17 +142,31 @@ struct snesimage_ctx {
 
 namespace {
 
-int32_t alloc_workspace(snesimage_ctx *c, uint32_t chunk) {
-    if (c->chunk_alloc >= chunk) return SNES_OK;
-    dfree(c->d_work); dfree(c->d_cand_tab); dfree(c->d_cand_lab); dfree(c->d_part); dfree(c->d_maps); dfree(c->d_mapsT);
-    HIPCHK(hipMalloc(&c->d_work, sizeof(float) * (size_t)c->G.cand_stride * chunk));
-    HIPCHK(hipMalloc(&c->d_cand_tab, sizeof(float) * 8 * (size_t)chunk));
-    HIPCHK(hipMalloc(&c->d_cand_lab, sizeof(float) * 3 * (size_t)chunk));
-    HIPCHK(hipMalloc(&c->d_part, sizeof(double) * (size_t)chunk * kMaxScales * 18));
+int32_t alloc_lane(snesimage_ctx *c, uint32_t chunk, float *&d_work, float *&d_cand_tab, float *&d_cand_lab, double *&d_part, uint8_t *&d_maps, uint8_t *&d_mapsT) {
+    dfree(d_work); dfree(d_cand_tab); dfree(d_cand_lab); dfree(d_part); dfree(d_maps); dfree(d_mapsT);
+    HIPCHK(hipMalloc(&d_work, sizeof(float) * (size_t)c->G.cand_stride * chunk));
+    HIPCHK(hipMalloc(&d_cand_tab, sizeof(float) * 8 * (size_t)chunk));
+    HIPCHK(hipMalloc(&d_cand_lab, sizeof(float) * 3 * (size_t)chunk));
+    HIPCHK(hipMalloc(&d_part, sizeof(double) * (size_t)chunk * kMaxScales * 18));
     if (c->dither) {
-        HIPCHK(hipMalloc(&c->d_maps, c->npx * (size_t)chunk));
-        HIPCHK(hipMalloc(&c->d_mapsT, c->npx * (size_t)chunk));
+        HIPCHK(hipMalloc(&d_maps, c->npx * (size_t)chunk));
+        HIPCHK(hipMalloc(&d_mapsT, c->npx * (size_t)chunk));
     }
+    return SNES_OK;
+}
+int32_t alloc_workspace(snesimage_ctx *c, uint32_t chunk) {
+    if (c->chunk_alloc >= chunk && c->extra.size() + 1 >= c->nlanes) return SNES_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto &L : c->extra) HIPCHK(hipStreamSynchronize(L.stream));
+    CHECK(alloc_lane(c, chunk, c->d_work, c->d_cand_tab, c->d_cand_lab, c->d_part, c->d_maps, c->d_mapsT));
+    if (!c->ev_ready) HIPCHK(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+    while (c->extra.size() + 1 < c->nlanes) {
+        snesimage_ctx::Lane L;
+        HIPCHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+        c->extra.push_back(L);
+    }
+    for (auto &L : c->extra) CHECK(alloc_lane(c, chunk, L.d_work, L.d_cand_tab, L.d_cand_lab, L.d_part, L.d_maps, L.d_mapsT));
     c->chunk_alloc = chunk;
     return SNES_OK;
 }
@@ -286,8 +305,7 @@ int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double
             } else hipLaunchKernelGGL((k_hpass<false, false>), grid, dim3(256), 0, c->stream, Hp);
         }
         if (s == 0 && c->timing) HIPCHK(hipEventRecord(tr.ev[2], c->stream));
-    }
-    for (int s = 0; s < G.nscales; s++) {
+        // the V pass of the same scale follows immediately, while its H output is still cache-resident
         if (s == 0 && c->timing) HIPCHK(hipEventRecord(tr.ev[3], c->stream));
         int ppv = 256 / G.sw[s];
         dim3 grid((npairs + ppv - 1) / ppv);
@@ -313,13 +331,38 @@ int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double
     return SNES_OK;
 }
 
-int32_t score_list(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t n, double *d_errors, int sp, int si, uint8_t *d_maps_out) {
+// Run score_chunk on an extra lane: its stream and per-chunk workspace stand in for the context's own.
+struct LaneScope {
+    snesimage_ctx *c; snesimage_ctx::Lane *L;
+    LaneScope(snesimage_ctx *c_, snesimage_ctx::Lane *L_) : c(c_), L(L_) { swap(); }
+    ~LaneScope() { swap(); }
+    void swap() { std::swap(c->stream, L->stream); std::swap(c->d_work, L->d_work); std::swap(c->d_cand_tab, L->d_cand_tab); std::swap(c->d_cand_lab, L->d_cand_lab);
+                  std::swap(c->d_part, L->d_part); std::swap(c->d_maps, L->d_maps); std::swap(c->d_mapsT, L->d_mapsT); }
+};
+
+// errors of candidate j of the list go to d_errors[err_offset + j * err_stride]
+int32_t score_list(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t n, double *d_errors, int err_stride, int err_offset, int sp, int si, uint8_t *d_maps_out) {
     CHECK(alloc_workspace(c, c->chunk));
     CHECK(ensure_tables(c));
     CHECK(ensure_source(c));
-    for (uint32_t c0 = 0; c0 < n; c0 += c->chunk) {
-        uint32_t nc = (n - c0 < c->chunk) ? (n - c0) : c->chunk;
-        CHECK(score_chunk(c, d_rgb5 + 3 * (size_t)c0, nc, d_errors, 1, (int)c0, sp, si, d_maps_out ? d_maps_out + (size_t)c0 * c->npx : nullptr));
+    const uint32_t nchunks = (n + c->chunk - 1) / c->chunk;
+    const uint32_t nl = nchunks < c->nlanes ? nchunks : c->nlanes;
+    if (nl > 1) {
+        HIPCHK(hipEventRecord(c->ev_ready, c->stream)); // pack, tables, candidates are ready
+        for (uint32_t l = 1; l < nl; l++) HIPCHK(hipStreamWaitEvent(c->extra[l - 1].stream, c->ev_ready, 0));
+    }
+    uint32_t i = 0;
+    for (uint32_t c0 = 0; c0 < n; c0 += c->chunk, i++) {
+        const uint32_t nc = (n - c0 < c->chunk) ? (n - c0) : c->chunk;
+        const uint32_t lane = i % nl;
+        uint8_t *mo = d_maps_out ? d_maps_out + (size_t)c0 * c->npx : nullptr;
+        const int eo = err_offset + (int)c0 * err_stride;
+        if (lane == 0) CHECK(score_chunk(c, d_rgb5 + 3 * (size_t)c0, nc, d_errors, err_stride, eo, sp, si, mo));
+        else { LaneScope ls(c, &c->extra[lane - 1]); CHECK(score_chunk(c, d_rgb5 + 3 * (size_t)c0, nc, d_errors, err_stride, eo, sp, si, mo)); }
+    }
+    for (uint32_t l = 1; l < nl; l++) {
+        HIPCHK(hipEventRecord(c->extra[l - 1].done, c->extra[l - 1].stream));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->extra[l - 1].done, 0));
     }
     return SNES_OK;
 }
@@ -438,6 +481,7 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     c->npx = (size_t)w * h;
     c->K = make_blur_constants();
     if (const char *e = getenv("SNES_CHUNK")) { int v = atoi(e); if (v > 0) c->chunk = (uint32_t)v; }
+    if (const char *e = getenv("SNES_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->nlanes = (uint32_t)v; }
     Geom &G = c->G;
     G.W = (int)w; G.H = (int)h; G.nscales = 0;
     // ssimulacra2's scale loop tests the size BEFORE downscaling (`if width < 8 || height < 8 { break }` then
@@ -520,6 +564,8 @@ void snesimage_destroy(snesimage_ctx *c) {
     dfree(c->d_pal_rgb8); dfree(c->d_pal_lin); dfree(c->d_pal_xyb); dfree(c->d_pal_lab); dfree(c->d_lin0); dfree(c->d_img1); dfree(c->d_img1T); dfree(c->d_mu1); dfree(c->d_s11);
     dfree(c->d_labpx); dfree(c->d_labpxT); dfree(c->d_work); dfree(c->d_cand_tab); dfree(c->d_cand_lab); dfree(c->d_part); dfree(c->d_maps); dfree(c->d_mapsT);
     dfree(c->d_cand); dfree(c->d_cand_sel); dfree(c->d_errs); dfree(c->d_errs_sel); dfree(c->d_inc_err); dfree(c->d_last); dfree(c->d_scratch_err); dfree(c->d_dummy_cand);
+    for (auto &L : c->extra) { if (L.stream) (void)hipStreamSynchronize(L.stream); dfree(L.d_work); dfree(L.d_cand_tab); dfree(L.d_cand_lab); dfree(L.d_part); dfree(L.d_maps); dfree(L.d_mapsT); if (L.done) (void)hipEventDestroy(L.done); if (L.stream) (void)hipStreamDestroy(L.stream); }
+    if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
     kmeans_free(c->km);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -569,7 +615,7 @@ int32_t snesimage_score_candidates_device(snesimage_ctx *c, uint32_t palette, ui
     if (n == 0) return SNES_OK;
     CHECK(set_device(c));
     CHECK(prep_for_slot(c, (int)palette, (int)index));
-    CHECK(score_list(c, d_rgb5, n, d_errors, (int)palette, (int)index, d_maps_out));
+    CHECK(score_list(c, d_rgb5, n, d_errors, 1, 0, (int)palette, (int)index, d_maps_out));
     return SNES_OK;
 }
 
@@ -595,7 +641,7 @@ int32_t snesimage_step_async(snesimage_ctx *c, uint32_t method, uint32_t palette
     if (method != SNES_METHOD_NES) CHECK(ensure_incumbent(c)); // lib.rs:199, 294 (nes: f64::MAX, lib.rs:250)
     CHECK(gen_candidates(c, method, palette, index, channel, seed, step_id, n));
     CHECK(prep_for_slot(c, (int)palette, (int)index));
-    CHECK(score_list(c, c->d_cand, n, c->d_errs, (int)palette, (int)index, nullptr));
+    CHECK(score_list(c, c->d_cand, n, c->d_errs, 1, 0, (int)palette, (int)index, nullptr));
     CHECK(commit(c, c->d_errs, n, method, palette, index));
     return SNES_OK;
 }
@@ -632,14 +678,8 @@ int32_t snesimage_step_begin(snesimage_ctx *c, uint32_t method, uint32_t palette
     HIPCHK(hipGetLastError());
     if (n_own) {
         CHECK(prep_for_slot(c, (int)palette, (int)index));
-        CHECK(alloc_workspace(c, c->chunk));
-        CHECK(ensure_tables(c));
-        CHECK(ensure_source(c));
-        for (uint32_t c0 = 0; c0 < n_own; c0 += c->chunk) {
-            uint32_t nc = (n_own - c0 < c->chunk) ? (n_own - c0) : c->chunk;
-            // candidate j of the shard is global candidate shard_rank + j*shard_count
-            CHECK(score_chunk(c, c->d_cand_sel + 3 * (size_t)c0, nc, d_errors, (int)shard_count, (int)(shard_rank + c0 * shard_count), (int)palette, (int)index, nullptr));
-        }
+        // candidate j of the shard is global candidate shard_rank + j*shard_count
+        CHECK(score_list(c, c->d_cand_sel, n_own, d_errors, (int)shard_count, (int)shard_rank, (int)palette, (int)index, nullptr));
     }
     c->pend = true; c->pend_n = n; c->pend_sp = palette; c->pend_si = index; c->pend_method = method;
     return SNES_OK;
