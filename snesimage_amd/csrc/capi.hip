@@ -4,6 +4,7 @@
 #include "kernels.hpp"
 #include "kernels_opt.hpp"
 #include "kernels_fast.hpp"
+#include "kernels_sparse.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -116,6 +117,14 @@ struct snesimage_ctx {
     // workspace above), so the HBM-bound H pass of one chunk overlaps the VALU-bound V pass of another.
     struct Lane { hipStream_t stream = nullptr; float *d_work = nullptr, *d_cand_tab = nullptr, *d_cand_lab = nullptr; double *d_part = nullptr; uint8_t *d_maps = nullptr, *d_mapsT = nullptr; hipEvent_t done = nullptr; };
     std::vector<Lane> extra; uint32_t nlanes = 2; hipEvent_t ev_ready = nullptr;
+    // Row-sparse scoring (kernels_sparse.hpp): one storage array for every lane's candidates plus the base image B
+    struct Sparse {
+        bool enabled = false; uint32_t min_n = 128; uint32_t cap = 0; // cap = candidates per lane the arrays were sized for
+        SparseGeom S{};
+        float *store = nullptr, *cand_tab = nullptr, *ckf = nullptr; double *cka = nullptr, *part = nullptr;
+        CandMeta *meta = nullptr; unsigned int *items = nullptr; int *item_count = nullptr; long long item_stride = 0;
+        uint4 *plist = nullptr; int *plist_count = nullptr; bool plist_valid = false;
+    } sp;
     // step state
     uint8_t *d_cand = nullptr; uint32_t cand_cap = 0;
     uint8_t *d_cand_sel = nullptr;
@@ -240,6 +249,7 @@ int32_t run_prep(snesimage_ctx *c, int mode, int sp, int si) {
     hipLaunchKernelGGL(k_prep, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, P);
     HIPCHK(hipGetLastError());
     c->pack_valid = true; c->pack_mode = mode; c->pack_sp = sp; c->pack_si = si;
+    c->sp.plist_valid = false; // the base image of the row-sparse path belongs to this pack
     return SNES_OK;
 }
 
@@ -331,6 +341,97 @@ int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double
     return SNES_OK;
 }
 
+// ---- row-sparse path ------------------------------------------------------------------------------------
+int32_t sparse_alloc(snesimage_ctx *c) {
+    auto &sp = c->sp;
+    if (sp.cap >= c->chunk) return SNES_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dfree(sp.store); dfree(sp.cand_tab); dfree(sp.ckf); dfree(sp.cka); dfree(sp.part); dfree(sp.meta); dfree(sp.items); dfree(sp.item_count); dfree(sp.plist); dfree(sp.plist_count);
+    const Geom &G = c->G;
+    SparseGeom &S = sp.S;
+    long long off = 0, okf = 0, oka = 0; int ro = 0;
+    for (int s = 0; s < G.nscales; s++) {
+        const long long N = (long long)G.sw[s] * G.sh[s];
+        S.off_lin[s] = off; if (s >= 1) off += 3 * N;
+        S.off_xyb[s] = off; if (s >= 1) off += 3 * N;
+        S.off_hout[s] = off; off += 9 * N;
+        S.off_ckf[s] = okf; okf += 3LL * (G.sh[s] + 5) * 18 * G.sw[s];
+        S.off_cka[s] = oka; oka += 3LL * (G.sh[s] + 5) * 6 * G.sw[s];
+        S.roff[s] = ro; ro += G.sh[s];
+    }
+    S.cand_stride = off;
+    const size_t ncap = (size_t)c->nlanes * c->chunk + 1; // + the base image B
+    sp.item_stride = (long long)c->chunk * G.sh[0] * 3;
+    HIPCHK(hipMalloc(&sp.store, sizeof(float) * (size_t)S.cand_stride * ncap));
+    HIPCHK(hipMalloc(&sp.cand_tab, sizeof(float) * 8 * ncap));
+    HIPCHK(hipMalloc(&sp.ckf, sizeof(float) * (size_t)okf));
+    HIPCHK(hipMalloc(&sp.cka, sizeof(double) * (size_t)oka));
+    HIPCHK(hipMalloc(&sp.part, sizeof(double) * ncap * kMaxScales * 18));
+    HIPCHK(hipMalloc(&sp.meta, sizeof(CandMeta) * ncap));
+    HIPCHK(hipMalloc(&sp.items, sizeof(unsigned int) * (size_t)sp.item_stride * kMaxScales * c->nlanes));
+    HIPCHK(hipMalloc(&sp.item_count, sizeof(int) * kMaxScales * (c->nlanes + 1)));
+    HIPCHK(hipMalloc(&sp.plist, sizeof(uint4) * c->npx));
+    HIPCHK(hipMalloc(&sp.plist_count, sizeof(int)));
+    sp.cap = c->chunk; sp.plist_valid = false;
+    return SNES_OK;
+}
+
+SparseParams sparse_params(snesimage_ctx *c, uint32_t lane) {
+    auto &sp = c->sp;
+    SparseParams P{};
+    P.G = c->G; P.S = sp.S; P.K = c->K; P.ncol = c->ncol; P.base = (int)(c->nlanes * c->chunk);
+    P.pack = c->d_pack; P.plist = sp.plist; P.plist_count = sp.plist_count;
+    P.pal_lin = c->d_pal_lin; P.pal_xyb = c->d_pal_xyb; P.cand_tab = sp.cand_tab;
+    P.img1 = c->d_img1; P.mu1 = c->d_mu1; P.s11 = c->d_s11;
+    P.store = sp.store; P.meta = sp.meta;
+    P.items = sp.items + (size_t)lane * sp.item_stride * kMaxScales; P.item_count = sp.item_count + (size_t)lane * kMaxScales; P.item_stride = sp.item_stride;
+    P.ckf = sp.ckf; P.cka = sp.cka; P.part = sp.part;
+    return P;
+}
+
+// B of the current slot: compact list of contested pixels, then the pipeline once with checkpoints (main stream)
+int32_t sparse_base_pass(snesimage_ctx *c) {
+    auto &sp = c->sp;
+    const Geom &G = c->G;
+    if (!sp.plist_valid) {
+        HIPCHK(hipMemsetAsync(sp.plist_count, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(k_build_plist, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, c->d_pack, (int)c->npx, sp.plist, sp.plist_count);
+        SparseParams P = sparse_params(c, 0);
+        P.is_base = 1; P.ncand = 1; P.k0 = P.base;
+        P.item_count = sp.item_count + (size_t)c->nlanes * kMaxScales; // the base pass has its own counters; it borrows lane 0's item list
+        HIPCHK(hipMemsetAsync(P.item_count, 0, sizeof(int) * kMaxScales, c->stream));
+        hipLaunchKernelGGL(k_sparse_scan, dim3(1), dim3(256), 0, c->stream, P);
+        hipLaunchKernelGGL(k_sparse_down, dim3(1), dim3(256), 0, c->stream, P);
+        hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((G.sh[0] * 3 + 63) / 64), (unsigned)G.nscales), dim3(64), 0, c->stream, P);
+        hipLaunchKernelGGL(k_sparse_v, dim3(3, (unsigned)G.nscales), dim3(256), 0, c->stream, P);
+        HIPCHK(hipGetLastError());
+        sp.plist_valid = true;
+    }
+    return SNES_OK;
+}
+
+int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, const uint8_t *d_rgb5, uint32_t nc, double *d_errors, int err_stride, int err_offset) {
+    auto &sp = c->sp;
+    const Geom &G = c->G;
+    SparseParams P = sparse_params(c, lane);
+    P.is_base = 0; P.ncand = (int)nc; P.k0 = (int)(lane * c->chunk);
+    snesimage_ctx::TimingRec tr{}; tr.n = nc;
+    if (c->timing) { for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&tr.ev[i])); HIPCHK(hipEventRecord(tr.ev[0], stream)); }
+    hipLaunchKernelGGL(k_candidate_tables, dim3((nc + 63) / 64), dim3(64), 0, stream, d_rgb5, (int)nc, c->d_eotf, sp.cand_tab + 8 * (size_t)P.k0);
+    HIPCHK(hipMemsetAsync(P.item_count, 0, sizeof(int) * kMaxScales, stream));
+    hipLaunchKernelGGL(k_sparse_scan, dim3(nc), dim3(256), 0, stream, P);
+    hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P);
+    if (c->timing) HIPCHK(hipEventRecord(tr.ev[1], stream));
+    hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)(((size_t)nc * G.sh[0] * 3 + 63) / 64), (unsigned)G.nscales), dim3(64), 0, stream, P);
+    if (c->timing) { HIPCHK(hipEventRecord(tr.ev[2], stream)); HIPCHK(hipEventRecord(tr.ev[3], stream)); }
+    hipLaunchKernelGGL(k_sparse_v, dim3(nc * 3, (unsigned)G.nscales), dim3(256), 0, stream, P);
+    if (c->timing) HIPCHK(hipEventRecord(tr.ev[4], stream));
+    hipLaunchKernelGGL(k_final_score, dim3((nc + 63) / 64), dim3(64), 0, stream, sp.part + (size_t)P.k0 * G.nscales * 18, (int)nc, G, d_errors, err_stride, err_offset);
+    HIPCHK(hipGetLastError());
+    if (c->timing) { HIPCHK(hipEventRecord(tr.ev[5], stream)); c->t_pending.push_back(tr); }
+    return SNES_OK;
+}
+
 // Run score_chunk on an extra lane: its stream and per-chunk workspace stand in for the context's own.
 struct LaneScope {
     snesimage_ctx *c; snesimage_ctx::Lane *L;
@@ -347,6 +448,8 @@ int32_t score_list(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t n, double *
     CHECK(ensure_source(c));
     const uint32_t nchunks = (n + c->chunk - 1) / c->chunk;
     const uint32_t nl = nchunks < c->nlanes ? nchunks : c->nlanes;
+    const bool sparse = c->sp.enabled && !d_maps_out && sp >= 0 && n >= c->sp.min_n && c->pack_mode == 2;
+    if (sparse) { CHECK(sparse_alloc(c)); CHECK(sparse_base_pass(c)); }
     if (nl > 1) {
         HIPCHK(hipEventRecord(c->ev_ready, c->stream)); // pack, tables, candidates are ready
         for (uint32_t l = 1; l < nl; l++) HIPCHK(hipStreamWaitEvent(c->extra[l - 1].stream, c->ev_ready, 0));
@@ -357,6 +460,7 @@ int32_t score_list(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t n, double *
         const uint32_t lane = i % nl;
         uint8_t *mo = d_maps_out ? d_maps_out + (size_t)c0 * c->npx : nullptr;
         const int eo = err_offset + (int)c0 * err_stride;
+        if (sparse) { CHECK(sparse_score_chunk(c, lane, lane == 0 ? c->stream : c->extra[lane - 1].stream, d_rgb5 + 3 * (size_t)c0, nc, d_errors, err_stride, eo)); continue; }
         if (lane == 0) CHECK(score_chunk(c, d_rgb5 + 3 * (size_t)c0, nc, d_errors, err_stride, eo, sp, si, mo));
         else { LaneScope ls(c, &c->extra[lane - 1]); CHECK(score_chunk(c, d_rgb5 + 3 * (size_t)c0, nc, d_errors, err_stride, eo, sp, si, mo)); }
     }
@@ -482,6 +586,9 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     c->K = make_blur_constants();
     if (const char *e = getenv("SNES_CHUNK")) { int v = atoi(e); if (v > 0) c->chunk = (uint32_t)v; }
     if (const char *e = getenv("SNES_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->nlanes = (uint32_t)v; }
+    c->sp.enabled = (h == 256) && !c->dither && !c->perceptual; // the row-sparse path covers the RGB / no-dither remap at the full size
+    if (const char *e = getenv("SNES_SPARSE")) c->sp.enabled = c->sp.enabled && atoi(e) != 0;
+    if (const char *e = getenv("SNES_SPARSE_MIN")) { int v = atoi(e); if (v >= 1) c->sp.min_n = (uint32_t)v; }
     Geom &G = c->G;
     G.W = (int)w; G.H = (int)h; G.nscales = 0;
     // ssimulacra2's scale loop tests the size BEFORE downscaling (`if width < 8 || height < 8 { break }` then
@@ -566,6 +673,7 @@ void snesimage_destroy(snesimage_ctx *c) {
     dfree(c->d_cand); dfree(c->d_cand_sel); dfree(c->d_errs); dfree(c->d_errs_sel); dfree(c->d_inc_err); dfree(c->d_last); dfree(c->d_scratch_err); dfree(c->d_dummy_cand);
     for (auto &L : c->extra) { if (L.stream) (void)hipStreamSynchronize(L.stream); dfree(L.d_work); dfree(L.d_cand_tab); dfree(L.d_cand_lab); dfree(L.d_part); dfree(L.d_maps); dfree(L.d_mapsT); if (L.done) (void)hipEventDestroy(L.done); if (L.stream) (void)hipStreamDestroy(L.stream); }
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+    { auto &q = c->sp; dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.plist_count); }
     kmeans_free(c->km);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -589,6 +697,7 @@ int32_t snesimage_set_chunk(snesimage_ctx *c, uint32_t chunk) {
     CHECK(set_device(c));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->chunk = chunk;
+    c->sp.cap = 0; c->sp.plist_valid = false; // storage indices of the row-sparse path depend on the chunk size
     return SNES_OK;
 }
 
