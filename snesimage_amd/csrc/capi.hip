@@ -225,7 +225,7 @@ int32_t ensure_source(snesimage_ctx *c) {
         hipLaunchKernelGGL((k_vpass<false, true, false>), dim3((3 + ppv - 1) / ppv), dim3(256), 0, c->stream, Vp);
     }
     for (int s = 0; s < G.nscales; s++)
-        if (c->fast_mask & (1 << s)) {
+        if ((c->fast_mask & (1 << s)) || c->sp.enabled) { // the row-sparse path reads the blocked layouts at every scale
             const int N = G.sw[s] * G.sh[s];
             hipLaunchKernelGGL(k_relayout, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_img1 + G.src_off[s], G.sw[s], G.sh[s], c->d_img1R4 + G.src_off[s], c->d_img1C4 + G.src_off[s]);
             hipLaunchKernelGGL(k_relayout, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_mu1 + G.src_off[s], G.sw[s], G.sh[s], c->d_mu1R4 + G.src_off[s], (float *)nullptr);
@@ -349,19 +349,20 @@ int32_t sparse_alloc(snesimage_ctx *c) {
     dfree(sp.store); dfree(sp.cand_tab); dfree(sp.ckf); dfree(sp.cka); dfree(sp.part); dfree(sp.meta); dfree(sp.items); dfree(sp.item_count); dfree(sp.plist); dfree(sp.plist_count);
     const Geom &G = c->G;
     SparseGeom &S = sp.S;
-    long long off = 0, okf = 0, oka = 0; int ro = 0;
+    long long off = 0, okf = 0, oka = 0; int go = 0;
     for (int s = 0; s < G.nscales; s++) {
         const long long N = (long long)G.sw[s] * G.sh[s];
         S.off_lin[s] = off; if (s >= 1) off += 3 * N;
-        S.off_xyb[s] = off; if (s >= 1) off += 3 * N;
+        S.off_xybC[s] = off; if (s >= 1) off += 3 * N;
+        S.off_xybR[s] = off; if (s >= 1) off += 3 * N;
         S.off_hout[s] = off; off += 9 * N;
-        S.off_ckf[s] = okf; okf += 3LL * (G.sh[s] + 5) * 18 * G.sw[s];
-        S.off_cka[s] = oka; oka += 3LL * (G.sh[s] + 5) * 6 * G.sw[s];
-        S.roff[s] = ro; ro += G.sh[s];
+        S.off_ckf[s] = okf; okf += 3LL * (G.sh[s] / 4 + 2) * 18 * G.sw[s];
+        S.off_cka[s] = oka; oka += 3LL * (G.sh[s] / 4 + 2) * 6 * G.sw[s];
+        S.goff[s] = go; go += G.sh[s] / 4;
     }
     S.cand_stride = off;
     const size_t ncap = (size_t)c->nlanes * c->chunk + 1; // + the base image B
-    sp.item_stride = (long long)c->chunk * G.sh[0] * 3;
+    sp.item_stride = (long long)c->chunk * (G.sh[0] / 4) * 3;
     HIPCHK(hipMalloc(&sp.store, sizeof(float) * (size_t)S.cand_stride * ncap));
     HIPCHK(hipMalloc(&sp.cand_tab, sizeof(float) * 8 * ncap));
     HIPCHK(hipMalloc(&sp.ckf, sizeof(float) * (size_t)okf));
@@ -380,9 +381,9 @@ SparseParams sparse_params(snesimage_ctx *c, uint32_t lane) {
     auto &sp = c->sp;
     SparseParams P{};
     P.G = c->G; P.S = sp.S; P.K = c->K; P.ncol = c->ncol; P.base = (int)(c->nlanes * c->chunk);
-    P.pack = c->d_pack; P.plist = sp.plist; P.plist_count = sp.plist_count;
+    P.pack = c->d_pack; P.packC4 = c->d_packC4; P.packR4 = c->d_packR4; P.plist = sp.plist; P.plist_count = sp.plist_count;
     P.pal_lin = c->d_pal_lin; P.pal_xyb = c->d_pal_xyb; P.cand_tab = sp.cand_tab;
-    P.img1 = c->d_img1; P.mu1 = c->d_mu1; P.s11 = c->d_s11;
+    P.img1C4 = c->d_img1C4; P.img1R4 = c->d_img1R4; P.mu1R4 = c->d_mu1R4; P.s11R4 = c->d_s11R4;
     P.store = sp.store; P.meta = sp.meta;
     P.items = sp.items + (size_t)lane * sp.item_stride * kMaxScales; P.item_count = sp.item_count + (size_t)lane * kMaxScales; P.item_stride = sp.item_stride;
     P.ckf = sp.ckf; P.cka = sp.cka; P.part = sp.part;
@@ -401,8 +402,8 @@ int32_t sparse_base_pass(snesimage_ctx *c) {
         P.item_count = sp.item_count + (size_t)c->nlanes * kMaxScales; // the base pass has its own counters; it borrows lane 0's item list
         HIPCHK(hipMemsetAsync(P.item_count, 0, sizeof(int) * kMaxScales, c->stream));
         hipLaunchKernelGGL(k_sparse_scan, dim3(1), dim3(256), 0, c->stream, P);
-        hipLaunchKernelGGL(k_sparse_down, dim3(1), dim3(256), 0, c->stream, P);
-        hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((G.sh[0] * 3 + 63) / 64), (unsigned)G.nscales), dim3(64), 0, c->stream, P);
+        for (int s = 1; s < G.nscales; s++) hipLaunchKernelGGL(k_sparse_down, dim3(32), dim3(256), 0, c->stream, P, s); // B: every row, one launch per scale
+        hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((G.sh[0] / 4 * 3 + 15) / 16), (unsigned)G.nscales), dim3(64), 0, c->stream, P);
         hipLaunchKernelGGL(k_sparse_v, dim3(3, (unsigned)G.nscales), dim3(256), 0, c->stream, P);
         HIPCHK(hipGetLastError());
         sp.plist_valid = true;
@@ -420,9 +421,9 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     hipLaunchKernelGGL(k_candidate_tables, dim3((nc + 63) / 64), dim3(64), 0, stream, d_rgb5, (int)nc, c->d_eotf, sp.cand_tab + 8 * (size_t)P.k0);
     HIPCHK(hipMemsetAsync(P.item_count, 0, sizeof(int) * kMaxScales, stream));
     hipLaunchKernelGGL(k_sparse_scan, dim3(nc), dim3(256), 0, stream, P);
-    hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P);
+    hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P, 0);
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[1], stream));
-    hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)(((size_t)nc * G.sh[0] * 3 + 63) / 64), (unsigned)G.nscales), dim3(64), 0, stream, P);
+    hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)(((size_t)nc * (G.sh[0] / 4) * 3 + 15) / 16), (unsigned)G.nscales), dim3(64), 0, stream, P);
     if (c->timing) { HIPCHK(hipEventRecord(tr.ev[2], stream)); HIPCHK(hipEventRecord(tr.ev[3], stream)); }
     hipLaunchKernelGGL(k_sparse_v, dim3(nc * 3, (unsigned)G.nscales), dim3(256), 0, stream, P);
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[4], stream));

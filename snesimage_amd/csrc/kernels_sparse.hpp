@@ -1,70 +1,75 @@
-// snesimage_amd/csrc/kernels_sparse.hpp — row-sparse ("delta") scoring of candidate palettes.
+// snesimage_amd/csrc/kernels_sparse.hpp — group-sparse ("delta") scoring of candidate palettes.
 //
 // Observation (measured on the BASELINE workload): replacing one palette entry by a random colour
 // changes few pixels.  Let B be the image in which every pixel of the slot's subpalette takes its
 // best *other* entry (the pack's fixed colour index); a candidate differs from B only at the pixels
-// it wins — a median of ~40 pixels in ~20 of the 256 rows, clustered in the subpalette's tiles.
+// it wins — a median of ~40 pixels in ~20 of the 256 rows, clustered in the subpalette's 8x8 tiles.
 //
 // Every stage of ssimulacra2 is causal along its sweep, so everything computed before the first
 // changed input is bit-identical to what the same stage computes for B:
 //   * H pass: an output row depends only on its input row  -> only changed rows are recomputed;
 //   * V pass + maps + pooling sums: a column's recurrence state and its running sums at step n
-//     depend only on rows < n+5                              -> resume from B's checkpoint at the
-//     first changed row; columns left of the first changed column (minus the filter's reach) are
-//     B's outright;
+//     depend only on rows < n+5  -> resume from B's checkpoint at the first changed row; columns left
+//     of the first changed column (minus the filter's reach) are B's outright;
 //   * downscale/XYB: a pixel of scale s depends on its 2^s x 2^s block -> only changed rows.
-// B itself is scored once per slot (it is the pseudo-candidate "all rows changed, wins nothing")
-// and leaves, in its own compact storage, dense row-major planes plus one checkpoint per row.
-// Results are bit-identical to the dense kernels (same operations in the same order; tests compare
-// the two paths), the work per candidate drops by the fraction of rows/columns it leaves untouched.
+// The unit of change is a *group* of four consecutive rows (4g..4g+3): it matches the 16-byte,
+// four-rows-per-lane accesses of the V pass and the four-lane quads of the H pass, and changed rows
+// come in runs anyway (tiles are 8 rows tall).  B itself is scored once per slot — it is the
+// pseudo-candidate "every group changed, wins nothing" — and leaves, in its own storage, all planes
+// plus one V-pass checkpoint per group.  Results are bit-identical to the dense kernels (same
+// operations in the same order; tests compare the two paths); the work per candidate shrinks to the
+// groups and columns it actually touches.
 //
-// Compact per-candidate storage (slot j = index of the row in the candidate's ascending changed-row
-// list of that scale): lin[s][j][3][W_s], xyb[s][j][3][W_s], hout[s][j][9][W_s].
+// Per-candidate storage, slot j = index of the group in the candidate's ascending changed-group list
+// of that scale (for B: j = g):
+//   lin [s][j][3][4][W]        linear RGB rows (input of the next downscale)
+//   xybC[s][j][3][W/4][4][4]   XYB, "C4" inside the group: [x/4][row][x%4]   (H-pass input, lane = row)
+//   xybR[s][j][3][W][4]        XYB, "R4" inside the group: [x][row]          (V-pass maps, lane = column)
+//   hout[s][j][9][W/64][64][4] H-pass output, "XT4" inside the group: [x/64][x%64][row]
 #pragma once
 #include "kernels.hpp"
 
 namespace snes {
 
-constexpr int kRowsTotal = 504; // 256 + 128 + 64 + 32 + 16 + 8
+constexpr int kGroupsTotal = 126; // 64 + 32 + 16 + 8 + 4 + 2
 
 struct CandMeta {
-    int nrows[kMaxScales];
-    int xmin;          // smallest x of a won pixel (W if none)
-    int won;           // number of won pixels
-    unsigned char rows[kRowsTotal]; // per scale: ascending changed rows
-    short slot[kRowsTotal];         // per scale: row -> slot, -1 if unchanged
+    int ngroups[kMaxScales];
+    int xmin;                          // smallest x of a won pixel (W if none)
+    int won;                           // number of won pixels
+    unsigned char glist[kGroupsTotal + 2]; // per scale: ascending changed groups
+    short gslot[kGroupsTotal];             // per scale: group -> slot, -1 if unchanged
 };
 
 struct SparseGeom {
-    long long off_lin[kMaxScales], off_xyb[kMaxScales], off_hout[kMaxScales]; // floats, inside one candidate's storage
-    long long cand_stride;                                                   // floats per candidate
-    long long off_ckf[kMaxScales], off_cka[kMaxScales];                      // checkpoint arrays (floats / doubles)
-    int roff[kMaxScales];                                                    // offset of scale s inside CandMeta::rows / slot
+    long long off_lin[kMaxScales], off_xybC[kMaxScales], off_xybR[kMaxScales], off_hout[kMaxScales]; // floats inside one candidate's storage
+    long long cand_stride;
+    long long off_ckf[kMaxScales], off_cka[kMaxScales]; // checkpoint arrays of B
+    int goff[kMaxScales];                               // offset of scale s inside CandMeta::glist / gslot
 };
 
 struct SparseParams {
     Geom G; SparseGeom S; BlurK K;
     int ncand, k0, base, ncol, is_base; // candidates of this launch occupy storage indices [k0, k0+ncand); base = index of B
-    const unsigned long long *pack; // row-major
+    const unsigned long long *pack, *packC4, *packR4;
     const uint4 *plist; const int *plist_count; // contested pixels of the slot: {px, rgb, thr, 0}
     const float *pal_lin, *pal_xyb, *cand_tab;
-    const float *img1, *mu1, *s11; // source arrays, row-major, + G.src_off[s]
+    const float *img1C4, *img1R4, *mu1R4, *s11R4; // source arrays in the blocked layouts, + G.src_off[s]
     float *store; CandMeta *meta;
-    unsigned int *items; int *item_count; long long item_stride; // per scale: items[s*item_stride + i] = cand*1024 + j*4 + ch
+    unsigned int *items; int *item_count; long long item_stride; // per scale: items[s*item_stride + i] = cand*256 + slot*4 + ch
     float *ckf; double *cka; double *part;
 };
 
-__device__ __forceinline__ uint32_t sparse_ci(unsigned long long pk, uint32_t crgb, uint32_t ncol, bool is_base) {
-    const uint32_t lo = (uint32_t)pk, thr = (uint32_t)(pk >> 32);
-    return (!is_base && red_mean_key(crgb, lo & 0x00ffffffu) < thr) ? ncol : (lo >> 24);
+__device__ __forceinline__ uint32_t sparse_ci(uint32_t lo, uint32_t thr, uint32_t crgb, uint32_t ncol) {
+    return red_mean_key(crgb, lo & 0x00ffffffu) < thr ? ncol : (lo >> 24); // B passes crgb with thr ignored: see callers
 }
 
-// ---- which rows does each candidate change? --------------------------------------------------------
+// ---- which groups does each candidate change? ---------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sparse_scan(SparseParams P) {
     __shared__ unsigned int s_mask[8];
     __shared__ int s_xmin, s_won;
-    __shared__ int s_flag[256];
-    __shared__ int s_base[kMaxScales];
+    __shared__ int s_flag[64];
+    __shared__ int s_base;
     const Geom &G = P.G;
     const int t = threadIdx.x;
     const int k = P.is_base ? P.base : P.k0 + (int)blockIdx.x;
@@ -88,37 +93,40 @@ __global__ __launch_bounds__(256) void k_sparse_scan(SparseParams P) {
     CandMeta *M = P.meta + k;
     if (t == 0) { M->xmin = s_xmin; M->won = s_won; }
     for (int s = 0; s < G.nscales; s++) {
-        const int Hs = G.sh[s];
+        const int NG = G.sh[s] >> 2;
         int flag = 0;
-        if (t < Hs) {
-            const int lo = t << s, len = 1 << s; // rows [lo, lo+len) of scale 0 (H = 256: Hs << s == H)
-            const unsigned int w = s_mask[lo >> 5];
-            const unsigned int m = (len >= 32) ? 0xffffffffu : (((1u << len) - 1u) << (lo & 31));
-            flag = (w & m) != 0u;
+        if (t < NG) { // group t of scale s covers scale-0 rows [4t << s, (4t+4) << s)
+            const int lo = (4 * t) << s, len = 4 << s;
+            for (int w = lo >> 5; w <= (lo + len - 1) >> 5; w++) {
+                const int b0 = max(lo, w << 5) & 31, b1 = min(lo + len, (w + 1) << 5) - (w << 5); // bits [b0, b1) of word w
+                const unsigned int m = (b1 - b0 >= 32) ? 0xffffffffu : (((1u << (b1 - b0)) - 1u) << b0);
+                flag |= (s_mask[w] & m) != 0u;
+            }
         }
-        s_flag[t] = flag;
+        if (t < 64) s_flag[t] = flag;
         __syncthreads();
         int below = 0, total = 0;
-        for (int i = 0; i < Hs; i++) { const int f = s_flag[i]; total += f; if (i < t) below += f; }
-        if (t < Hs) {
-            M->slot[P.S.roff[s] + t] = flag ? (short)below : (short)-1;
-            if (flag) M->rows[P.S.roff[s] + below] = (unsigned char)t;
+        for (int i = 0; i < NG; i++) { const int f = s_flag[i]; total += f; if (i < t) below += f; }
+        if (t < NG) {
+            M->gslot[P.S.goff[s] + t] = flag ? (short)below : (short)-1;
+            if (flag) M->glist[P.S.goff[s] + below] = (unsigned char)t;
         }
-        if (t == 0) { M->nrows[s] = total; s_base[s] = total ? atomicAdd(&P.item_count[s], total * 3) : 0; }
+        if (t == 0) { M->ngroups[s] = total; s_base = total ? atomicAdd(&P.item_count[s], total * 3) : 0; }
         __syncthreads();
-        // work items of the H pass: (candidate, slot, channel)
-        for (int i = t; i < total * 3; i += 256) P.items[(size_t)s * P.item_stride + s_base[s] + i] = (unsigned int)k * 1024u + (unsigned int)(i / 3) * 4u + (unsigned int)(i % 3);
+        for (int i = t; i < total * 3; i += 256) P.items[(size_t)s * P.item_stride + s_base + i] = (unsigned int)k * 256u + (unsigned int)(i / 3) * 4u + (unsigned int)(i % 3);
         __syncthreads();
     }
 }
 
-// ---- downscale chain + XYB on changed rows only ------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sparse_down(SparseParams P) {
+// ---- downscale chain + XYB on changed groups only -------------------------------------------------------
+// base: grid.x blocks share the rows of each scale (launched once per scale, P.ncand = scale to do);
+// candidates: one block per candidate walks the scales itself.
+__global__ __launch_bounds__(256) void k_sparse_down(SparseParams P, int only_scale) {
     __shared__ float s_lin[256 * 3];
     const Geom &G = P.G;
     const int t = threadIdx.x;
-    const int k = P.is_base ? P.base : P.k0 + (int)blockIdx.x;
     const bool is_base = P.is_base != 0;
+    const int k = is_base ? P.base : P.k0 + (int)blockIdx.x;
     for (int i = t; i < (P.ncol + 2) * 3; i += 256) s_lin[i] = P.pal_lin[i];
     __syncthreads();
     if (t < 3 && !is_base) s_lin[3 * P.ncol + t] = P.cand_tab[8 * (size_t)k + t];
@@ -127,12 +135,15 @@ __global__ __launch_bounds__(256) void k_sparse_down(SparseParams P) {
     const CandMeta *M = P.meta + k;
     float *mine = P.store + (size_t)k * P.S.cand_stride;
     const float *basep = P.store + (size_t)P.base * P.S.cand_stride;
-    for (int s = 1; s < G.nscales; s++) {
+    const int s_lo = only_scale > 0 ? only_scale : 1, s_hi = only_scale > 0 ? only_scale + 1 : G.nscales;
+    const int part0 = is_base ? (int)blockIdx.x : 0, nparts = is_base ? (int)gridDim.x : 1;
+    for (int s = s_lo; s < s_hi; s++) {
         const int Ws = G.sw[s], Wp = G.sw[s - 1];
-        const int n = M->nrows[s];
-        for (int i = t; i < n * Ws; i += 256) {
-            const int j = i / Ws, x = i - j * Ws;
-            const int y = M->rows[P.S.roff[s] + j];
+        const int n = M->ngroups[s];
+        for (int i = part0 * 256 + t; i < n * 4 * Ws; i += 256 * nparts) {
+            const int j = i / (4 * Ws), r = (i / Ws) & 3, x = i % Ws;
+            const int g = M->glist[P.S.goff[s] + j];
+            const int y = 4 * g + r;
             float v[3];
             if (s == 1) {
                 float sum[3] = {0.0f, 0.0f, 0.0f};
@@ -140,119 +151,160 @@ __global__ __launch_bounds__(256) void k_sparse_down(SparseParams P) {
                 for (int iy = 0; iy < 2; iy++)
 #pragma unroll
                     for (int ix = 0; ix < 2; ix++) {
-                        const uint32_t ci = sparse_ci(P.pack[(size_t)(2 * y + iy) * G.W + 2 * x + ix], crgb, (uint32_t)P.ncol, is_base);
+                        const unsigned long long w = P.pack[(size_t)(2 * y + iy) * G.W + 2 * x + ix];
+                        const uint32_t ci = is_base ? ((uint32_t)w >> 24) : sparse_ci((uint32_t)w, (uint32_t)(w >> 32), crgb, (uint32_t)P.ncol);
                         sum[0] += s_lin[3 * ci]; sum[1] += s_lin[3 * ci + 1]; sum[2] += s_lin[3 * ci + 2];
                     }
                 v[0] = sum[0] * 0.25f; v[1] = sum[1] * 0.25f; v[2] = sum[2] * 0.25f;
             } else {
-                // rows 2y, 2y+1 of scale s-1: the candidate's own compact row if it changed, else B's
-                const short sl0 = M->slot[P.S.roff[s - 1] + 2 * y], sl1 = M->slot[P.S.roff[s - 1] + 2 * y + 1];
-                const float *r0 = sl0 >= 0 ? mine + P.S.off_lin[s - 1] + (size_t)sl0 * 3 * Wp : basep + P.S.off_lin[s - 1] + (size_t)(2 * y) * 3 * Wp;
-                const float *r1 = sl1 >= 0 ? mine + P.S.off_lin[s - 1] + (size_t)sl1 * 3 * Wp : basep + P.S.off_lin[s - 1] + (size_t)(2 * y + 1) * 3 * Wp;
+                // rows 2y, 2y+1 of scale s-1 live in one group: the candidate's own if it changed, else B's
+                const int gp = (2 * y) >> 2, rp = (2 * y) & 3;
+                const short sl = M->gslot[P.S.goff[s - 1] + gp];
+                const float *grp = sl >= 0 ? mine + P.S.off_lin[s - 1] + (size_t)sl * 12 * Wp : basep + P.S.off_lin[s - 1] + (size_t)gp * 12 * Wp;
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
+                    const float *r0 = grp + (size_t)(c * 4 + rp) * Wp, *r1 = r0 + Wp;
                     float sum = 0.0f;
-                    sum += r0[c * Wp + 2 * x]; sum += r0[c * Wp + 2 * x + 1]; sum += r1[c * Wp + 2 * x]; sum += r1[c * Wp + 2 * x + 1];
+                    sum += r0[2 * x]; sum += r0[2 * x + 1]; sum += r1[2 * x]; sum += r1[2 * x + 1];
                     v[c] = sum * 0.25f;
                 }
             }
             float X, Y, B;
             linear_to_positive_xyb(v[0], v[1], v[2], X, Y, B);
-            float *ol = mine + P.S.off_lin[s] + (size_t)j * 3 * Ws, *ox = mine + P.S.off_xyb[s] + (size_t)j * 3 * Ws;
-            ol[x] = v[0]; ol[Ws + x] = v[1]; ol[2 * Ws + x] = v[2];
-            ox[x] = X; ox[Ws + x] = Y; ox[2 * Ws + x] = B;
+            float *ol = mine + P.S.off_lin[s] + (size_t)j * 12 * Ws;
+            float *oc = mine + P.S.off_xybC[s] + (size_t)j * 12 * Ws, *orr = mine + P.S.off_xybR[s] + (size_t)j * 12 * Ws;
+            const float xyb[3] = {X, Y, B};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                ol[(size_t)(c * 4 + r) * Ws + x] = v[c];
+                oc[(size_t)c * 4 * Ws + (size_t)(x >> 2) * 16 + r * 4 + (x & 3)] = xyb[c];
+                orr[(size_t)c * 4 * Ws + (size_t)x * 4 + r] = xyb[c];
+            }
         }
         __syncthreads(); // the rows written above are read by this block at the next scale
     }
 }
 
-// ---- H pass of changed rows: one lane = one (candidate, row slot, channel) ----------------------------
+// recurrence steps, identical to kernels_fast.hpp
+#define SNES_HSTEP(SUM, A, B, OUT)                                                   \
+    {                                                                                \
+        float o1_ = (SUM) * n2_0, o3_ = (SUM) * n2_1, o5_ = (SUM) * n2_2;            \
+        o1_ = fmaf(-1.0f, B[0], o1_); o3_ = fmaf(-1.0f, B[1], o3_); o5_ = fmaf(-1.0f, B[2], o5_); \
+        o1_ = fmaf(mp_0, A[0], o1_); o3_ = fmaf(mp_1, A[1], o3_); o5_ = fmaf(mp_2, A[2], o5_);    \
+        B[0] = o1_; B[1] = o3_; B[2] = o5_;                                          \
+        OUT = o1_ + o3_ + o5_;                                                       \
+    }
+#define SNES_VSTEP(SUM, A, B, OUT)                                                   \
+    {                                                                                \
+        float o1_ = fmaf(A[0], d1_0, B[0]), o3_ = fmaf(A[1], d1_1, B[1]), o5_ = fmaf(A[2], d1_2, B[2]); \
+        o1_ = fmaf((SUM), n2_0, -o1_); o3_ = fmaf((SUM), n2_1, -o3_); o5_ = fmaf((SUM), n2_2, -o5_);    \
+        B[0] = o1_; B[1] = o3_; B[2] = o5_;                                          \
+        OUT = o1_ + o3_ + o5_;                                                       \
+    }
+
+// ---- H pass of changed groups: one lane quad = the four rows of one (candidate, group slot, channel) ----
 __global__ __launch_bounds__(64) void k_sparse_h(SparseParams P) {
     __shared__ float s_lut[3][256];
+    __shared__ float s_tr[3][64 * 5];
     const Geom &G = P.G;
     const int s = blockIdx.y;
     if (s >= G.nscales) return;
     const int lane = threadIdx.x;
     const int count = P.item_count[s];
-    const int i0 = blockIdx.x * 64;
+    const int i0 = blockIdx.x * 16;
     if (i0 >= count) return;
     const bool S0 = (s == 0);
     if (S0) {
         for (int i = lane; i < 3 * 256; i += 64) { int c = i >> 8, j = i & 255; s_lut[c][j] = (j < P.ncol + 2) ? P.pal_xyb[3 * j + c] : 0.0f; }
         __syncthreads();
     }
-    const bool valid = (i0 + lane) < count;
-    const unsigned int it = P.items[(size_t)s * P.item_stride + (valid ? i0 + lane : i0)];
-    const int k = (int)(it >> 10), j = (int)((it >> 2) & 255u), ch = (int)(it & 3u);
+    const int qi = i0 + (lane >> 2);
+    const bool valid = qi < count;
+    const unsigned int it = P.items[(size_t)s * P.item_stride + (valid ? qi : i0)];
+    const int k = (int)(it >> 8), j = (int)((it >> 2) & 63u), ch = (int)(it & 3u);
     const bool is_base = (k == P.base);
     const CandMeta *M = P.meta + k;
     const int W = G.sw[s], H = G.sh[s];
-    const int y = M->rows[P.S.roff[s] + j];
+    const int r = lane & 3;
+    const int y = 4 * (int)M->glist[P.S.goff[s] + j] + r;
     const size_t ns = (size_t)W * H;
     const float cand_v = is_base ? 0.0f : P.cand_tab[8 * (size_t)k + 3 + ch];
     const uint32_t crgb = is_base ? 0u : __float_as_uint(P.cand_tab[8 * (size_t)k + 6]);
-    const float4 *in1 = reinterpret_cast<const float4 *>(P.img1 + G.src_off[s] + (size_t)ch * ns + (size_t)y * W);
-    const float4 *in2 = S0 ? nullptr : reinterpret_cast<const float4 *>(P.store + (size_t)k * P.S.cand_stride + P.S.off_xyb[s] + (size_t)j * 3 * W + (size_t)ch * W);
-    const uint4 *pk = S0 ? reinterpret_cast<const uint4 *>(P.pack + (size_t)y * W) : nullptr;
-    float *out = P.store + (size_t)k * P.S.cand_stride + P.S.off_hout[s] + (size_t)j * 9 * W + (size_t)(ch * 3) * W;
+    const uint32_t never = is_base ? 0u : 0xffffffffu; // thr & never == 0 for B: it wins nothing
+    const float4 *in1 = reinterpret_cast<const float4 *>(P.img1C4 + G.src_off[s] + (size_t)ch * ns) + y;                   // C4: + g*H
+    const uint4 *pk = S0 ? reinterpret_cast<const uint4 *>(P.packC4) + 2 * (size_t)y : nullptr;                            // + g*2H
+    const float4 *in2 = S0 ? nullptr : reinterpret_cast<const float4 *>(P.store + (size_t)k * P.S.cand_stride + P.S.off_xybC[s] + (size_t)j * 12 * W + (size_t)ch * 4 * W) + r; // + g*4
+    float *out = P.store + (size_t)k * P.S.cand_stride + P.S.off_hout[s] + (size_t)j * 36 * W + (size_t)(ch * 3) * 4 * W;
 
     const float n2_0 = P.K.n2[0], n2_1 = P.K.n2[1], n2_2 = P.K.n2[2];
     const float mp_0 = -P.K.d1[0], mp_1 = -P.K.d1[1], mp_2 = -P.K.d1[2];
-    float pv[3][3], pv2[3][3];
+    float sa[3][3], sb[3][3];
 #pragma unroll
     for (int p = 0; p < 3; p++)
 #pragma unroll
-        for (int q = 0; q < 3; q++) { pv[p][q] = 0.0f; pv2[p][q] = 0.0f; }
+        for (int q = 0; q < 3; q++) { sa[p][q] = 0.0f; sb[p][q] = 0.0f; }
     float4 r1[5], r2[5];
 #pragma unroll
     for (int a = 0; a < 5; a++) { r1[a] = make_float4(0.f, 0.f, 0.f, 0.f); r2[a] = r1[a]; }
     const int G4 = W >> 2;
+    uint4 n_pa = make_uint4(0, 0, 0, 0), n_pb = n_pa;
+    r1[0] = in1[0];
+    if (S0) { n_pa = pk[0]; n_pb = pk[1]; } else r2[0] = in2[0];
+    const int li = lane & 3, k4 = lane & ~3;
     for (int g0 = 0; g0 <= G4; g0 += 5) {
 #pragma unroll
         for (int u = 0; u < 5; u++) {
             const int g = g0 + u;
             if (g > G4) break;
-            const int ua = (u + 2) % 5, ub = (u + 3) % 5;
-            if (g < G4) {
-                r1[u] = in1[g];
-                if (S0) {
-                    const uint4 a = pk[2 * g], b = pk[2 * g + 1];
-                    const unsigned long long w0 = ((unsigned long long)a.y << 32) | a.x, w1 = ((unsigned long long)a.w << 32) | a.z;
-                    const unsigned long long w2 = ((unsigned long long)b.y << 32) | b.x, w3 = ((unsigned long long)b.w << 32) | b.z;
-                    const uint32_t c0 = sparse_ci(w0, crgb, (uint32_t)P.ncol, is_base), c1 = sparse_ci(w1, crgb, (uint32_t)P.ncol, is_base);
-                    const uint32_t c2 = sparse_ci(w2, crgb, (uint32_t)P.ncol, is_base), c3 = sparse_ci(w3, crgb, (uint32_t)P.ncol, is_base);
-                    r2[u].x = c0 == (uint32_t)P.ncol ? cand_v : s_lut[ch][c0]; r2[u].y = c1 == (uint32_t)P.ncol ? cand_v : s_lut[ch][c1];
-                    r2[u].z = c2 == (uint32_t)P.ncol ? cand_v : s_lut[ch][c2]; r2[u].w = c3 == (uint32_t)P.ncol ? cand_v : s_lut[ch][c3];
-                } else r2[u] = in2[g];
-            } else { r1[u] = make_float4(0.f, 0.f, 0.f, 0.f); r2[u] = r1[u]; }
+            const int un = (u + 1) % 5, ua = (u + 2) % 5, ub = (u + 3) % 5;
+            const uint4 c_pa = n_pa, c_pb = n_pb;
+            if (g + 1 < G4) {
+                r1[un] = in1[(size_t)(g + 1) * H];
+                if (S0) { n_pa = pk[(size_t)(g + 1) * H * 2]; n_pb = pk[(size_t)(g + 1) * H * 2 + 1]; } else r2[un] = in2[(size_t)(g + 1) * 4];
+            } else { r1[un] = make_float4(0.f, 0.f, 0.f, 0.f); r2[un] = r1[un]; n_pa = make_uint4(0, 0, 0, 0); n_pb = n_pa; }
+            if (S0 && g < G4) {
+                const uint32_t c0 = sparse_ci(c_pa.x, c_pa.y & never, crgb, (uint32_t)P.ncol), c1 = sparse_ci(c_pa.z, c_pa.w & never, crgb, (uint32_t)P.ncol);
+                const uint32_t c2 = sparse_ci(c_pb.x, c_pb.y & never, crgb, (uint32_t)P.ncol), c3 = sparse_ci(c_pb.z, c_pb.w & never, crgb, (uint32_t)P.ncol);
+                r2[u].x = c0 == (uint32_t)P.ncol ? cand_v : s_lut[ch][c0]; r2[u].y = c1 == (uint32_t)P.ncol ? cand_v : s_lut[ch][c1];
+                r2[u].z = c2 == (uint32_t)P.ncol ? cand_v : s_lut[ch][c2]; r2[u].w = c3 == (uint32_t)P.ncol ? cand_v : s_lut[ch][c3];
+            }
             const float v1[4] = {r1[u].x, r1[u].y, r1[u].z, r1[u].w}, v2[4] = {r2[u].x, r2[u].y, r2[u].z, r2[u].w};
             const float l1[4] = {r1[ua].z, r1[ua].w, r1[ub].x, r1[ub].y}, l2[4] = {r2[ua].z, r2[ua].w, r2[ub].x, r2[ub].y};
             float outp[3][4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const float sums[3] = {l2[q] + v2[q], (l2[q] * l2[q]) + (v2[q] * v2[q]), (l1[q] * l2[q]) + (v1[q] * v2[q])};
+                const float s0 = l2[q] + v2[q];
+                const float s1 = (l2[q] * l2[q]) + (v2[q] * v2[q]);
+                const float s2 = (l1[q] * l2[q]) + (v1[q] * v2[q]);
+                if ((q & 1) == 0) { SNES_HSTEP(s0, sa[0], sb[0], outp[0][q]) SNES_HSTEP(s1, sa[1], sb[1], outp[1][q]) SNES_HSTEP(s2, sa[2], sb[2], outp[2][q]) }
+                else { SNES_HSTEP(s0, sb[0], sa[0], outp[0][q]) SNES_HSTEP(s1, sb[1], sa[1], outp[1][q]) SNES_HSTEP(s2, sb[2], sa[2], outp[2][q]) }
+            }
+            if (g >= 1) { // 4x4 transpose inside the quad: lane li then holds column 4(g-1)+li of the group's four rows
 #pragma unroll
                 for (int p = 0; p < 3; p++) {
-                    float o1 = sums[p] * n2_0, o3 = sums[p] * n2_1, o5 = sums[p] * n2_2;
-                    o1 = fmaf(-1.0f, pv2[p][0], o1); o3 = fmaf(-1.0f, pv2[p][1], o3); o5 = fmaf(-1.0f, pv2[p][2], o5);
-                    pv2[p][0] = pv[p][0]; pv2[p][1] = pv[p][1]; pv2[p][2] = pv[p][2];
-                    o1 = fmaf(mp_0, pv[p][0], o1); o3 = fmaf(mp_1, pv[p][1], o3); o5 = fmaf(mp_2, pv[p][2], o5);
-                    pv[p][0] = o1; pv[p][1] = o3; pv[p][2] = o5;
-                    outp[p][q] = o1 + o3 + o5;
+                    s_tr[p][lane * 5 + 0] = outp[p][0]; s_tr[p][lane * 5 + 1] = outp[p][1]; s_tr[p][lane * 5 + 2] = outp[p][2]; s_tr[p][lane * 5 + 3] = outp[p][3];
                 }
-            }
-            if (g >= 1 && valid) {
+                __syncthreads();
+                const int x = ((g - 1) << 2) + li;
+                const size_t o = ((size_t)(x >> 6) << 8) + ((size_t)(x & 63) << 2);
+                if (valid) {
 #pragma unroll
-                for (int p = 0; p < 3; p++)
-                    *reinterpret_cast<float4 *>(out + (size_t)p * W + ((g - 1) << 2)) = make_float4(outp[p][0], outp[p][1], outp[p][2], outp[p][3]);
+                    for (int p = 0; p < 3; p++) {
+                        float4 v;
+                        v.x = s_tr[p][(k4 + 0) * 5 + li]; v.y = s_tr[p][(k4 + 1) * 5 + li]; v.z = s_tr[p][(k4 + 2) * 5 + li]; v.w = s_tr[p][(k4 + 3) * 5 + li];
+                        *reinterpret_cast<float4 *>(out + (size_t)p * 4 * W + o) = v;
+                    }
+                }
+                __syncthreads();
             }
         }
     }
 }
 
-// ---- V pass + maps, resumed from B's checkpoint at the first changed row -------------------------------
+// ---- V pass + maps, resumed from B's checkpoint at the first changed group --------------------------------
 // block = 256 threads = 256/W_s (candidate, channel) pairs; thread = one image column.
-// Checkpoint record r (0 <= r <= H+4) of B: recurrence state before step n = r-4 and pooling sums of rows < r-4.
+// Checkpoint record g (0 <= g <= H/4 + 1) of B: recurrence state before group iteration g (steps 4g-4..4g-1)
+// and pooling sums of rows < 4g-4; record H/4+1 holds the final sums.
 __global__ __launch_bounds__(256) void k_sparse_v(SparseParams P) {
     __shared__ float s_lut[3][256];
     __shared__ double red[256][6];
@@ -262,7 +314,8 @@ __global__ __launch_bounds__(256) void k_sparse_v(SparseParams P) {
     const int W = G.sw[s], H = G.sh[s];
     const int t = threadIdx.x;
     const int ppw = 256 / W;
-    const int npairs = P.is_base ? 3 : P.ncand * 3;
+    const bool is_base = P.is_base != 0;
+    const int npairs = is_base ? 3 : P.ncand * 3;
     if ((int)blockIdx.x * ppw >= npairs) return;
     const bool S0 = (s == 0);
     if (S0) {
@@ -273,118 +326,159 @@ __global__ __launch_bounds__(256) void k_sparse_v(SparseParams P) {
     const int pair_raw = blockIdx.x * ppw + ql;
     const bool active = pair_raw < npairs;
     const int pair = active ? pair_raw : 0;
-    const int k = P.is_base ? P.base : P.k0 + pair / 3, ch = pair % 3;
-    const bool is_base = P.is_base != 0;
+    const int k = is_base ? P.base : P.k0 + pair / 3, ch = pair % 3;
     const size_t ns = (size_t)W * H;
+    const int H4 = H >> 2;
     const CandMeta *M = P.meta + k;
-    const short *slot = M->slot + P.S.roff[s];
-    const int nrows = M->nrows[s];
-    const int r0 = nrows ? (int)M->rows[P.S.roff[s]] : H + 4;
+    const short *gslot = M->gslot + P.S.goff[s];
+    const int ng = M->ngroups[s];
     const int cmin = (M->xmin >> s) - 5; // columns <= cmin see only unchanged inputs
+    const bool skip = !is_base && (ng == 0 || x <= cmin);
+    const int gs = skip ? H4 + 1 : (is_base ? 0 : (int)M->glist[P.S.goff[s]]);
     const float cand_v = is_base ? 0.0f : P.cand_tab[8 * (size_t)k + 3 + ch];
     const uint32_t crgb = is_base ? 0u : __float_as_uint(P.cand_tab[8 * (size_t)k + 6]);
+    const uint32_t never = is_base ? 0u : 0xffffffffu;
+    const float *lut = s_lut[ch];
     const float *mine = P.store + (size_t)k * P.S.cand_stride;
     const float *basep = P.store + (size_t)P.base * P.S.cand_stride;
-    const float *img1 = P.img1 + G.src_off[s] + (size_t)ch * ns, *mu1 = P.mu1 + G.src_off[s] + (size_t)ch * ns, *s11 = P.s11 + G.src_off[s] + (size_t)ch * ns;
-    // checkpoint arrays: ckf[s][ch][r][18][W], cka[s][ch][r][6][W]
-    float *ckf = P.ckf + P.S.off_ckf[s] + (size_t)ch * (H + 5) * 18 * W;
-    double *cka = P.cka + P.S.off_cka[s] + (size_t)ch * (H + 5) * 6 * W;
+    // hout of group g, plane p: float4 index (p*W) + ((x>>6)<<6) + (x&63) inside the group's 9*W float4s
+    const size_t hx = ((size_t)(x >> 6) << 6) + (size_t)(x & 63);
+    const float4 *hb = reinterpret_cast<const float4 *>(basep + P.S.off_hout[s]) + (size_t)(ch * 3) * W + hx;  // + g*9W
+    const float4 *hm = reinterpret_cast<const float4 *>(mine + P.S.off_hout[s]) + (size_t)(ch * 3) * W + hx;   // + slot*9W
+    const float4 *xb = S0 ? nullptr : reinterpret_cast<const float4 *>(basep + P.S.off_xybR[s]) + (size_t)ch * W + x; // + g*3W
+    const float4 *xm = S0 ? nullptr : reinterpret_cast<const float4 *>(mine + P.S.off_xybR[s]) + (size_t)ch * W + x;
+    const float4 *img1 = reinterpret_cast<const float4 *>(P.img1R4 + G.src_off[s] + (size_t)ch * ns) + x; // + g*W
+    const float4 *mu1 = reinterpret_cast<const float4 *>(P.mu1R4 + G.src_off[s] + (size_t)ch * ns) + x;
+    const float4 *s11 = reinterpret_cast<const float4 *>(P.s11R4 + G.src_off[s] + (size_t)ch * ns) + x;
+    const uint4 *pk = S0 ? reinterpret_cast<const uint4 *>(P.packR4) + 2 * (size_t)x : nullptr; // + g*2W
+    // checkpoints: ckf[s][ch][g][18][W], cka[s][ch][g][6][W]
+    float *ckf = P.ckf + P.S.off_ckf[s] + (size_t)ch * (H4 + 2) * 18 * W + x;
+    double *cka = P.cka + P.S.off_cka[s] + (size_t)ch * (H4 + 2) * 6 * W + x;
 
-    // does this wave have anything to recompute?  (a whole wave shares k unless W < 64; keep it per lane)
-    const bool skip = !is_base && (nrows == 0 || x <= cmin);
-    const int rs = skip ? H + 4 : (is_base ? 0 : r0);
-    float pv[3][3], pv2[3][3];
+    const float n2_0 = P.K.n2[0], n2_1 = P.K.n2[1], n2_2 = P.K.n2[2];
+    const float d1_0 = P.K.d1[0], d1_1 = P.K.d1[1], d1_2 = P.K.d1[2];
+    float sa[3][3], sb[3][3];
     double acc[6];
     if (is_base) {
 #pragma unroll
         for (int p = 0; p < 3; p++)
 #pragma unroll
-            for (int q = 0; q < 3; q++) { pv[p][q] = 0.0f; pv2[p][q] = 0.0f; }
+            for (int q = 0; q < 3; q++) { sa[p][q] = 0.0f; sb[p][q] = 0.0f; }
 #pragma unroll
         for (int q = 0; q < 6; q++) acc[q] = 0.0;
     } else {
-        const float *cf = ckf + (size_t)rs * 18 * W + x;
-        const double *ca = cka + (size_t)rs * 6 * W + x;
+        const float *cf = ckf + (size_t)gs * 18 * W;
+        const double *ca = cka + (size_t)gs * 6 * W;
 #pragma unroll
         for (int p = 0; p < 3; p++)
 #pragma unroll
-            for (int q = 0; q < 3; q++) { pv[p][q] = cf[(size_t)(p * 6 + q) * W]; pv2[p][q] = cf[(size_t)(p * 6 + 3 + q) * W]; }
+            for (int q = 0; q < 3; q++) { sa[p][q] = cf[(size_t)(p * 6 + q) * W]; sb[p][q] = cf[(size_t)(p * 6 + 3 + q) * W]; }
 #pragma unroll
         for (int q = 0; q < 6; q++) acc[q] = ca[(size_t)q * W];
     }
-    const float n2_0 = P.K.n2[0], n2_1 = P.K.n2[1], n2_2 = P.K.n2[2];
-    const float d1_0 = P.K.d1[0], d1_1 = P.K.d1[1], d1_2 = P.K.d1[2];
-    // the block's pairs may start at different rows: run from the smallest start, lanes idle until their own
-    for (int n = rs - 4; n < H; n++) {
-        if (is_base && active) { // record r = n + 4
-            float *cf = ckf + (size_t)(n + 4) * 18 * W + x;
-            double *ca = cka + (size_t)(n + 4) * 6 * W + x;
+    // ring: groups gs-3 .. gs-1 come from B (they precede the first changed group)
+    float4 ring[3][5];
 #pragma unroll
-            for (int p = 0; p < 3; p++)
+    for (int p = 0; p < 3; p++)
 #pragma unroll
-                for (int q = 0; q < 3; q++) { cf[(size_t)(p * 6 + q) * W] = pv[p][q]; cf[(size_t)(p * 6 + 3 + q) * W] = pv2[p][q]; }
-#pragma unroll
-            for (int q = 0; q < 6; q++) ca[(size_t)q * W] = acc[q];
-        }
-        const int b = n + 4, tp = n - 6;
-        float in[3] = {0.0f, 0.0f, 0.0f}, top[3] = {0.0f, 0.0f, 0.0f};
-        if (b < H) {
-            const short sl = slot[b];
-            const float *row = sl >= 0 ? mine + P.S.off_hout[s] + (size_t)sl * 9 * W : basep + P.S.off_hout[s] + (size_t)b * 9 * W;
-            in[0] = row[(size_t)(ch * 3) * W + x]; in[1] = row[(size_t)(ch * 3 + 1) * W + x]; in[2] = row[(size_t)(ch * 3 + 2) * W + x];
-        }
-        if (tp >= 0) {
-            const short sl = slot[tp];
-            const float *row = sl >= 0 ? mine + P.S.off_hout[s] + (size_t)sl * 9 * W : basep + P.S.off_hout[s] + (size_t)tp * 9 * W;
-            top[0] = row[(size_t)(ch * 3) * W + x]; top[1] = row[(size_t)(ch * 3 + 1) * W + x]; top[2] = row[(size_t)(ch * 3 + 2) * W + x];
-        }
-        float outp[3];
+        for (int a = 0; a < 5; a++) ring[p][a] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto hload = [&](int g, int p) -> float4 { // group g of plane p: the candidate's if it changed, else B's
+        const short sl = gslot[g];
+        return sl >= 0 ? hm[(size_t)sl * 9 * W + (size_t)p * W] : hb[(size_t)g * 9 * W + (size_t)p * W];
+    };
+    // slot layout inside the 5-unrolled loop is u = (g - gs) % 5: group gs -> slot 0, gs-1 -> slot 4, gs-2 -> 3, gs-3 -> 2
+    if (!skip) {
 #pragma unroll
         for (int p = 0; p < 3; p++) {
-            const float sum = top[p] + in[p];
-            float o1 = fmaf(pv[p][0], d1_0, pv2[p][0]);
-            float o3 = fmaf(pv[p][1], d1_1, pv2[p][1]);
-            float o5 = fmaf(pv[p][2], d1_2, pv2[p][2]);
-            o1 = fmaf(sum, n2_0, -o1); o3 = fmaf(sum, n2_1, -o3); o5 = fmaf(sum, n2_2, -o5);
-            pv2[p][0] = pv[p][0]; pv2[p][1] = pv[p][1]; pv2[p][2] = pv[p][2];
-            pv[p][0] = o1; pv[p][1] = o3; pv[p][2] = o5;
-            outp[p] = o1 + o3 + o5;
-        }
-        if (n >= 0) {
-            const size_t idx = (size_t)n * W + x;
-            const float m1 = mu1[idx], m2 = outp[0], v11 = s11[idx], v22 = outp[1], v12 = outp[2];
-            const float i1 = img1[idx];
-            float i2;
-            if (S0) {
-                const uint32_t ci = sparse_ci(P.pack[idx], crgb, (uint32_t)P.ncol, is_base);
-                i2 = (ci == (uint32_t)P.ncol) ? cand_v : s_lut[ch][ci];
-            } else {
-                const short sl = slot[n];
-                i2 = sl >= 0 ? mine[P.S.off_xyb[s] + (size_t)sl * 3 * W + (size_t)ch * W + x] : basep[P.S.off_xyb[s] + (size_t)n * 3 * W + (size_t)ch * W + x];
-            }
-            const float mu11 = m1 * m1, mu22 = m2 * m2, mu12 = m1 * m2;
-            const float mu_diff = m1 - m2;
-            const float num_m = fmaf(mu_diff, -mu_diff, 1.0f);
-            const float num_s = fmaf(2.0f, v12 - mu12, 0.0009f);
-            const float denom_s = (v11 - mu11) + (v22 - mu22) + 0.0009f;
-            double d = 1.0 - (double)((num_m * num_s) / denom_s);
-            d = d > 0.0 ? d : 0.0;
-            acc[0] += d;
-            const double dd = d * d;
-            acc[1] += dd * dd;
-            const double d1 = (1.0 + (double)fabsf(i2 - m2)) / (1.0 + (double)fabsf(i1 - m1)) - 1.0;
-            const double art = d1 > 0.0 ? d1 : 0.0;
-            const double det = (-d1) > 0.0 ? (-d1) : 0.0;
-            acc[2] += art;
-            const double a2 = art * art;
-            acc[3] += a2 * a2;
-            acc[4] += det;
-            const double l2 = det * det;
-            acc[5] += l2 * l2;
+            if (gs < H4) ring[p][0] = hload(gs, p);
+            if (gs - 1 >= 0) ring[p][4] = hload(gs - 1, p);
+            if (gs - 2 >= 0) ring[p][3] = hload(gs - 2, p);
+            if (gs - 3 >= 0) ring[p][2] = hload(gs - 3, p);
         }
     }
-    if (is_base && active) { // final record r = H + 4
-        double *ca = cka + (size_t)(H + 4) * 6 * W + x;
+    // map inputs of row group g-1 travel one iteration ahead of their use
+    float4 n_i1 = make_float4(0.f, 0.f, 0.f, 0.f), n_m1 = n_i1, n_s11 = n_i1, n_x = n_i1;
+    uint4 n_pa = make_uint4(0, 0, 0, 0), n_pb = n_pa;
+    if (!skip && gs >= 1) {
+        const int gm = gs - 1;
+        n_i1 = img1[(size_t)gm * W]; n_m1 = mu1[(size_t)gm * W]; n_s11 = s11[(size_t)gm * W];
+        if (S0) { n_pa = pk[(size_t)gm * W * 2]; n_pb = pk[(size_t)gm * W * 2 + 1]; }
+        else { const short sl = gslot[gm]; n_x = sl >= 0 ? xm[(size_t)sl * 3 * W] : xb[(size_t)gm * 3 * W]; }
+    }
+    for (int g0 = gs; g0 <= H4; g0 += 5) {
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+            const int g = g0 + u;
+            if (g > H4) break;
+            if (is_base && active) { // record g
+                float *cf = ckf + (size_t)g * 18 * W;
+                double *ca = cka + (size_t)g * 6 * W;
+#pragma unroll
+                for (int p = 0; p < 3; p++)
+#pragma unroll
+                    for (int q = 0; q < 3; q++) { cf[(size_t)(p * 6 + q) * W] = sa[p][q]; cf[(size_t)(p * 6 + 3 + q) * W] = sb[p][q]; }
+#pragma unroll
+                for (int q = 0; q < 6; q++) ca[(size_t)q * W] = acc[q];
+            }
+            const int un = (u + 1) % 5, ua = (u + 2) % 5, ub = (u + 3) % 5;
+            const float4 c_i1 = n_i1, c_m1 = n_m1, c_s11 = n_s11, c_x = n_x; const uint4 c_pa = n_pa, c_pb = n_pb;
+            if (g + 1 < H4) { ring[0][un] = hload(g + 1, 0); ring[1][un] = hload(g + 1, 1); ring[2][un] = hload(g + 1, 2); }
+            else { ring[0][un] = make_float4(0.f, 0.f, 0.f, 0.f); ring[1][un] = ring[0][un]; ring[2][un] = ring[0][un]; }
+            if (g < H4) {
+                n_i1 = img1[(size_t)g * W]; n_m1 = mu1[(size_t)g * W]; n_s11 = s11[(size_t)g * W];
+                if (S0) { n_pa = pk[(size_t)g * W * 2]; n_pb = pk[(size_t)g * W * 2 + 1]; }
+                else { const short sl = gslot[g]; n_x = sl >= 0 ? xm[(size_t)sl * 3 * W] : xb[(size_t)g * 3 * W]; }
+            }
+            float i2v[4] = {c_x.x, c_x.y, c_x.z, c_x.w};
+            if (S0 && g >= 1) {
+                const uint32_t c0 = sparse_ci(c_pa.x, c_pa.y & never, crgb, (uint32_t)P.ncol), c1 = sparse_ci(c_pa.z, c_pa.w & never, crgb, (uint32_t)P.ncol);
+                const uint32_t c2 = sparse_ci(c_pb.x, c_pb.y & never, crgb, (uint32_t)P.ncol), c3 = sparse_ci(c_pb.z, c_pb.w & never, crgb, (uint32_t)P.ncol);
+                i2v[0] = c0 == (uint32_t)P.ncol ? cand_v : lut[c0]; i2v[1] = c1 == (uint32_t)P.ncol ? cand_v : lut[c1];
+                i2v[2] = c2 == (uint32_t)P.ncol ? cand_v : lut[c2]; i2v[3] = c3 == (uint32_t)P.ncol ? cand_v : lut[c3];
+            }
+            const float i1v[4] = {c_i1.x, c_i1.y, c_i1.z, c_i1.w}, m1v[4] = {c_m1.x, c_m1.y, c_m1.z, c_m1.w}, s11v[4] = {c_s11.x, c_s11.y, c_s11.z, c_s11.w};
+            float in[3][4], top[3][4];
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+                in[p][0] = ring[p][u].x; in[p][1] = ring[p][u].y; in[p][2] = ring[p][u].z; in[p][3] = ring[p][u].w;
+                top[p][0] = ring[p][ua].z; top[p][1] = ring[p][ua].w; top[p][2] = ring[p][ub].x; top[p][3] = ring[p][ub].y;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float outp[3];
+                if ((q & 1) == 0) {
+                    SNES_VSTEP(top[0][q] + in[0][q], sa[0], sb[0], outp[0]) SNES_VSTEP(top[1][q] + in[1][q], sa[1], sb[1], outp[1]) SNES_VSTEP(top[2][q] + in[2][q], sa[2], sb[2], outp[2])
+                } else {
+                    SNES_VSTEP(top[0][q] + in[0][q], sb[0], sa[0], outp[0]) SNES_VSTEP(top[1][q] + in[1][q], sb[1], sa[1], outp[1]) SNES_VSTEP(top[2][q] + in[2][q], sb[2], sa[2], outp[2])
+                }
+                if (g >= 1) {
+                    const float m1 = m1v[q], m2 = outp[0], v11 = s11v[q], v22 = outp[1], v12 = outp[2];
+                    const float i1 = i1v[q], i2 = i2v[q];
+                    const float mu11 = m1 * m1, mu22 = m2 * m2, mu12 = m1 * m2;
+                    const float mu_diff = m1 - m2;
+                    const float num_m = fmaf(mu_diff, -mu_diff, 1.0f);
+                    const float num_s = fmaf(2.0f, v12 - mu12, 0.0009f);
+                    const float denom_s = (v11 - mu11) + (v22 - mu22) + 0.0009f;
+                    double d = 1.0 - (double)((num_m * num_s) / denom_s);
+                    d = d > 0.0 ? d : 0.0;
+                    acc[0] += d;
+                    const double dd = d * d;
+                    acc[1] += dd * dd;
+                    const double d1 = (1.0 + (double)fabsf(i2 - m2)) / (1.0 + (double)fabsf(i1 - m1)) - 1.0;
+                    const double art = d1 > 0.0 ? d1 : 0.0;
+                    const double det = (-d1) > 0.0 ? (-d1) : 0.0;
+                    acc[2] += art;
+                    const double a2 = art * art;
+                    acc[3] += a2 * a2;
+                    acc[4] += det;
+                    const double l2 = det * det;
+                    acc[5] += l2 * l2;
+                }
+            }
+        }
+    }
+    if (is_base && active) { // final record
+        double *ca = cka + (size_t)(H4 + 1) * 6 * W;
 #pragma unroll
         for (int q = 0; q < 6; q++) ca[(size_t)q * W] = acc[q];
     }
@@ -404,8 +498,10 @@ __global__ __launch_bounds__(256) void k_sparse_v(SparseParams P) {
         for (int q = 0; q < 6; q++) o[q] = red[t][q];
     }
 }
+#undef SNES_HSTEP
+#undef SNES_VSTEP
 
-// contested pixels of a slot (thr != 0) -> compact list, built once per slot by k_prep's companion
+// contested pixels of a slot (thr != 0) -> compact list, built once per slot
 __global__ __launch_bounds__(256) void k_build_plist(const unsigned long long *__restrict__ pack, int npx, uint4 *__restrict__ plist, int *__restrict__ count) {
     int px = blockIdx.x * blockDim.x + threadIdx.x;
     if (px >= npx) return;
