@@ -124,6 +124,7 @@ struct snesimage_ctx {
         float *store = nullptr, *cand_tab = nullptr, *ckf = nullptr; double *cka = nullptr, *part = nullptr;
         CandMeta *meta = nullptr; unsigned int *items = nullptr; int *item_count = nullptr; long long item_stride = 0;
         uint4 *plist = nullptr; int *plist_count = nullptr; bool plist_valid = false;
+        hipStream_t base_stream = nullptr; hipEvent_t ev_base_in = nullptr, ev_base_done = nullptr; // B's H and V passes run beside the candidates' scan/down/H
     } sp;
     // step state
     uint8_t *d_cand = nullptr; uint32_t cand_cap = 0;
@@ -369,7 +370,12 @@ int32_t sparse_alloc(snesimage_ctx *c) {
     HIPCHK(hipMalloc(&sp.cka, sizeof(double) * (size_t)oka));
     HIPCHK(hipMalloc(&sp.part, sizeof(double) * ncap * kMaxScales * 18));
     HIPCHK(hipMalloc(&sp.meta, sizeof(CandMeta) * ncap));
-    HIPCHK(hipMalloc(&sp.items, sizeof(unsigned int) * (size_t)sp.item_stride * kMaxScales * c->nlanes));
+    HIPCHK(hipMalloc(&sp.items, sizeof(unsigned int) * (size_t)sp.item_stride * kMaxScales * (c->nlanes + 1)));
+    if (!sp.base_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&sp.base_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&sp.ev_base_in, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&sp.ev_base_done, hipEventDisableTiming));
+    }
     HIPCHK(hipMalloc(&sp.item_count, sizeof(int) * kMaxScales * (c->nlanes + 1)));
     HIPCHK(hipMalloc(&sp.plist, sizeof(uint4) * c->npx));
     HIPCHK(hipMalloc(&sp.plist_count, sizeof(int)));
@@ -385,7 +391,7 @@ SparseParams sparse_params(snesimage_ctx *c, uint32_t lane) {
     P.pal_lin = c->d_pal_lin; P.pal_xyb = c->d_pal_xyb; P.cand_tab = sp.cand_tab;
     P.img1C4 = c->d_img1C4; P.img1R4 = c->d_img1R4; P.mu1R4 = c->d_mu1R4; P.s11R4 = c->d_s11R4;
     P.store = sp.store; P.meta = sp.meta;
-    P.items = sp.items + (size_t)lane * sp.item_stride * kMaxScales; P.item_count = sp.item_count + (size_t)lane * kMaxScales; P.item_stride = sp.item_stride;
+    P.items = sp.items + (size_t)lane * sp.item_stride * kMaxScales; P.item_count = sp.item_count + (size_t)lane * kMaxScales; P.item_stride = sp.item_stride; // lane == nlanes: B
     P.ckf = sp.ckf; P.cka = sp.cka; P.part = sp.part;
     return P;
 }
@@ -397,15 +403,19 @@ int32_t sparse_base_pass(snesimage_ctx *c) {
     if (!sp.plist_valid) {
         HIPCHK(hipMemsetAsync(sp.plist_count, 0, sizeof(int), c->stream));
         hipLaunchKernelGGL(k_build_plist, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, c->d_pack, (int)c->npx, sp.plist, sp.plist_count);
-        SparseParams P = sparse_params(c, 0);
+        SparseParams P = sparse_params(c, c->nlanes); // B has its own item list and counters
         P.is_base = 1; P.ncand = 1; P.k0 = P.base;
-        P.item_count = sp.item_count + (size_t)c->nlanes * kMaxScales; // the base pass has its own counters; it borrows lane 0's item list
         HIPCHK(hipMemsetAsync(P.item_count, 0, sizeof(int) * kMaxScales, c->stream));
         hipLaunchKernelGGL(k_sparse_scan, dim3(1), dim3(256), 0, c->stream, P);
         for (int s = 1; s < G.nscales; s++) hipLaunchKernelGGL(k_sparse_down, dim3(32), dim3(256), 0, c->stream, P, s); // B: every row, one launch per scale
-        hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((G.sh[0] / 4 * 3 + 15) / 16), (unsigned)G.nscales), dim3(64), 0, c->stream, P);
-        hipLaunchKernelGGL(k_sparse_v, dim3(3, (unsigned)G.nscales), dim3(256), 0, c->stream, P);
+        // B's H and V passes are long single-image sweeps (latency-bound); they run on their own stream beside the
+        // candidates' scan / downscale / H pass, which only need B's linear-RGB rows.  The candidates' V pass waits for them.
+        HIPCHK(hipEventRecord(sp.ev_base_in, c->stream));
+        HIPCHK(hipStreamWaitEvent(sp.base_stream, sp.ev_base_in, 0));
+        hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((G.sh[0] / 4 * 3 + 15) / 16), (unsigned)G.nscales), dim3(64), 0, sp.base_stream, P);
+        hipLaunchKernelGGL(k_sparse_v, dim3(3, (unsigned)G.nscales), dim3(256), 0, sp.base_stream, P);
         HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(sp.ev_base_done, sp.base_stream));
         sp.plist_valid = true;
     }
     return SNES_OK;
@@ -423,7 +433,9 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     hipLaunchKernelGGL(k_sparse_scan, dim3(nc), dim3(256), 0, stream, P);
     hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P, 0);
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[1], stream));
-    hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)(((size_t)nc * (G.sh[0] / 4) * 3 + 15) / 16), (unsigned)G.nscales), dim3(64), 0, stream, P);
+    { size_t gx = ((size_t)nc * (G.sh[0] / 4) * 3 + 15) / 16; if (gx > 2048) gx = 2048; // grid-stride over the item quads
+      hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)gx, (unsigned)G.nscales), dim3(64), 0, stream, P); }
+    HIPCHK(hipStreamWaitEvent(stream, sp.ev_base_done, 0)); // checkpoints and H output of B
     if (c->timing) { HIPCHK(hipEventRecord(tr.ev[2], stream)); HIPCHK(hipEventRecord(tr.ev[3], stream)); }
     hipLaunchKernelGGL(k_sparse_v, dim3(nc * 3, (unsigned)G.nscales), dim3(256), 0, stream, P);
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[4], stream));
@@ -550,7 +562,7 @@ int32_t gen_candidates(snesimage_ctx *c, uint32_t method, uint32_t palette, uint
 uint32_t method_count(uint32_t method, uint32_t n_random) { return method == SNES_METHOD_RANDOM ? (n_random ? n_random : 64u) : (method == SNES_METHOD_CHANNEL ? 32u : kNesColorCount); }
 
 int32_t commit(snesimage_ctx *c, const double *d_errors, uint32_t n, uint32_t method, uint32_t palette, uint32_t index) {
-    hipLaunchKernelGGL(k_commit, dim3(1), dim3(64), 0, c->stream, d_errors, (int)n, c->d_cand, c->d_colors, (int)(palette * c->sub_size + index), method == SNES_METHOD_NES ? 1 : 0, c->d_inc_err,
+    hipLaunchKernelGGL(k_commit, dim3(1), dim3(256), 0, c->stream, d_errors, (int)n, c->d_cand, c->d_colors, (int)(palette * c->sub_size + index), method == SNES_METHOD_NES ? 1 : 0, c->d_inc_err,
                        c->d_last);
     HIPCHK(hipGetLastError());
     c->tables_valid = false;
@@ -674,7 +686,7 @@ void snesimage_destroy(snesimage_ctx *c) {
     dfree(c->d_cand); dfree(c->d_cand_sel); dfree(c->d_errs); dfree(c->d_errs_sel); dfree(c->d_inc_err); dfree(c->d_last); dfree(c->d_scratch_err); dfree(c->d_dummy_cand);
     for (auto &L : c->extra) { if (L.stream) (void)hipStreamSynchronize(L.stream); dfree(L.d_work); dfree(L.d_cand_tab); dfree(L.d_cand_lab); dfree(L.d_part); dfree(L.d_maps); dfree(L.d_mapsT); if (L.done) (void)hipEventDestroy(L.done); if (L.stream) (void)hipStreamDestroy(L.stream); }
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
-    { auto &q = c->sp; dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.plist_count); }
+    { auto &q = c->sp; if (q.base_stream) { (void)hipStreamSynchronize(q.base_stream); (void)hipStreamDestroy(q.base_stream); (void)hipEventDestroy(q.ev_base_in); (void)hipEventDestroy(q.ev_base_done); } dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.plist_count); }
     kmeans_free(c->km);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;

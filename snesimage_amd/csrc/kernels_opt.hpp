@@ -175,12 +175,28 @@ __global__ void k_shard_select(const uint8_t *__restrict__ cand, int n, int rank
 
 // Acceptance rule: ascending k, strict `<` against the running best starting from the incumbent
 // (lib.rs:216-219, 302-305) or from f64::MAX for the NES method (lib.rs:250, 258-261).
-__global__ void k_commit(const double *__restrict__ errors, int n, const uint8_t *__restrict__ cand, uint8_t *__restrict__ colors, int slot, int nes, double *__restrict__ inc_err,
-                         StepResult *__restrict__ last) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double best = nes ? 1.7976931348623157e308 : *inc_err;
-    int best_k = -1;
-    for (int k = 0; k < n; k++) { double e = errors[k]; if (e < best) { best = e; best_k = k; } }
+__global__ __launch_bounds__(256) void k_commit(const double *__restrict__ errors, int n, const uint8_t *__restrict__ cand, uint8_t *__restrict__ colors, int slot, int nes, double *__restrict__ inc_err,
+                                               StepResult *__restrict__ last) {
+    // The sequential scan "for k ascending: if e_k < best" ends on the FIRST index attaining the minimum, provided that
+    // minimum is < the starting value; a parallel (error, index) lexicographic minimum gives the same answer.
+    __shared__ double s_e[256];
+    __shared__ int s_k[256];
+    const int t = threadIdx.x;
+    double be = __longlong_as_double(0x7ff0000000000000ll); int bk = 0x7fffffff;
+    for (int k = t; k < n; k += 256) { const double e = errors[k]; if (e < be) { be = e; bk = k; } } // NaN never wins, as in the reference
+    s_e[t] = be; s_k[t] = bk;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (t < st) {
+            const double e2 = s_e[t + st]; const int k2 = s_k[t + st];
+            if (e2 < s_e[t] || (e2 == s_e[t] && k2 < s_k[t])) { s_e[t] = e2; s_k[t] = k2; }
+        }
+        __syncthreads();
+    }
+    if (t != 0) return;
+    const double start = nes ? 1.7976931348623157e308 : *inc_err;
+    double best = start; int best_k = -1;
+    if (s_k[0] != 0x7fffffff && s_e[0] < start) { best = s_e[0]; best_k = s_k[0]; }
     uint8_t c[3] = {colors[3 * slot], colors[3 * slot + 1], colors[3 * slot + 2]};
     uint8_t changed = 0;
     if (nes && best_k < 0) best_k = 0; // best_index = 0 (lib.rs:249)

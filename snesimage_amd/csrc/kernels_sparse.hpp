@@ -211,13 +211,13 @@ __global__ __launch_bounds__(64) void k_sparse_h(SparseParams P) {
     if (s >= G.nscales) return;
     const int lane = threadIdx.x;
     const int count = P.item_count[s];
-    const int i0 = blockIdx.x * 16;
-    if (i0 >= count) return;
+    if ((int)blockIdx.x * 16 >= count) return;
     const bool S0 = (s == 0);
     if (S0) {
         for (int i = lane; i < 3 * 256; i += 64) { int c = i >> 8, j = i & 255; s_lut[c][j] = (j < P.ncol + 2) ? P.pal_xyb[3 * j + c] : 0.0f; }
         __syncthreads();
     }
+    for (int i0 = blockIdx.x * 16; i0 < count; i0 += gridDim.x * 16) { // grid-stride over item quads: no empty waves
     const int qi = i0 + (lane >> 2);
     const bool valid = qi < count;
     const unsigned int it = P.items[(size_t)s * P.item_stride + (valid ? qi : i0)];
@@ -299,6 +299,7 @@ __global__ __launch_bounds__(64) void k_sparse_h(SparseParams P) {
             }
         }
     }
+    }
 }
 
 // ---- V pass + maps, resumed from B's checkpoint at the first changed group --------------------------------
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(64) void k_sparse_h(SparseParams P) {
 __global__ __launch_bounds__(256) void k_sparse_v(SparseParams P) {
     __shared__ float s_lut[3][256];
     __shared__ double red[256][6];
+    __shared__ short s_gslot[256];
     const Geom &G = P.G;
     const int s = blockIdx.y;
     if (s >= G.nscales) return;
@@ -330,7 +332,14 @@ __global__ __launch_bounds__(256) void k_sparse_v(SparseParams P) {
     const size_t ns = (size_t)W * H;
     const int H4 = H >> 2;
     const CandMeta *M = P.meta + k;
-    const short *gslot = M->gslot + P.S.goff[s];
+    // group -> slot table of this block's pairs, staged in LDS so the per-group pointer choice costs no global load
+    for (int i = t; i < ppw * H4; i += 256) {
+        const int pr = blockIdx.x * ppw + i / H4;
+        const int kk = is_base ? P.base : P.k0 + (pr < npairs ? pr : 0) / 3;
+        s_gslot[i] = (P.meta + kk)->gslot[P.S.goff[s] + i % H4];
+    }
+    __syncthreads();
+    const short *gslot = s_gslot + ql * H4;
     const int ng = M->ngroups[s];
     const int cmin = (M->xmin >> s) - 5; // columns <= cmin see only unchanged inputs
     const bool skip = !is_base && (ng == 0 || x <= cmin);

@@ -121,7 +121,7 @@ def test_kmeans_precondition_is_an_error(S, O):
 @pytest.mark.parametrize("flags,slot,n", [({}, (2, 3), 24), ({}, (7, 14), 9), ({"perceptual": True}, (0, 0), 6),
                                           ({"dither": True}, (5, 1), 6), ({"dither": True, "perceptual": True}, (1, 2), 3)])
 def test_score_candidates_parity_with_maps(S, O, img256_alpha, flags, slot, n):
-    import torch
+    from hipmem import DeviceArray
     g, o = pair(S, O, img256_alpha, 8, 15, **flags)
     o.initialize_tiles()
     o.recalculate_palettes()
@@ -130,13 +130,13 @@ def test_score_candidates_parity_with_maps(S, O, img256_alpha, flags, slot, n):
     cand[0] = o.palette[slot[0] * 15 + slot[1]]       # the incumbent colour itself
     cand[1] = o.palette[slot[0] * 15 + (slot[1] + 1) % 15]  # duplicate of a neighbouring entry: tie-break by index
     eo, mo = o.score_candidates(slot[0], slot[1], cand, want_maps=True)
-    d_c = torch.from_numpy(cand).cuda()
-    d_e = torch.zeros(n, dtype=torch.float64, device="cuda")
-    d_m = torch.zeros((n, 256, 256), dtype=torch.uint8, device="cuda")
-    g.score_candidates_device(slot[0], slot[1], d_c.data_ptr(), n, d_e.data_ptr(), d_m.data_ptr())
+    d_c = DeviceArray.from_numpy(cand)
+    d_e = DeviceArray(n, np.float64, fill=0)
+    d_m = DeviceArray((n, 256, 256), np.uint8, fill=0)
+    g.score_candidates_device(slot[0], slot[1], d_c.ptr, n, d_e.ptr, d_m.ptr)
     g.sync()
-    assert np.array_equal(d_m.cpu().numpy(), mo)                   # indices bit-exact
-    assert rel(d_e.cpu().numpy(), eo) < REL_ERR
+    assert np.array_equal(d_m.numpy(), mo)                   # indices bit-exact
+    assert rel(d_e.numpy(), eo) < REL_ERR
     assert rel(g.score_candidates(slot[0], slot[1], cand), eo) < REL_ERR
     assert rel(eo[0], o.error()) == 0.0 and rel(g.score_candidates(slot[0], slot[1], cand[:1])[0], g.error()) == 0.0
     assert np.array_equal(g.palette, o.palette) and np.array_equal(g.palette_map, o.palette_map)  # state untouched
@@ -257,7 +257,7 @@ def test_nes_steps(S, O):
 
 def test_split_phase_step_equals_plain_step(S, O, img256):
     """step_begin / (min-reduce) / step_commit with 2 shards on one GPU == step()."""
-    import torch
+    from hipmem import DeviceArray
     ref = S.OptimizedImage(img256, 8, 15)
     ref.initialize_tiles()
     ref.recalculate_palettes()
@@ -270,14 +270,15 @@ def test_split_phase_step_equals_plain_step(S, O, img256):
         shards.append(s)
     for i, (p, idx) in enumerate([(0, 0), (3, 7), (0, 0)]):
         e_ref, b_ref = ref.step(S.METHOD_RANDOM, p, idx, 0, 4, i, 40)
-        bufs = [torch.empty(40, dtype=torch.float64, device="cuda") for _ in range(2)]
+        bufs = [DeviceArray(40, np.float64, fill=0) for _ in range(2)]
         for r, s in enumerate(shards):
-            s.step_begin(S.METHOD_RANDOM, p, idx, 0, 4, i, 40, r, 2, bufs[r].data_ptr())
+            s.step_begin(S.METHOD_RANDOM, p, idx, 0, 4, i, 40, r, 2, bufs[r].ptr)
             s.sync()
-        assert torch.isinf(bufs[0][1::2]).all() and torch.isinf(bufs[1][0::2]).all()
-        red = torch.minimum(bufs[0], bufs[1])  # what the RCCL min-all-reduce produces
+        h0, h1 = bufs[0].numpy(), bufs[1].numpy()
+        assert np.isinf(h0[1::2]).all() and np.isinf(h1[0::2]).all()
+        red = DeviceArray.from_numpy(np.minimum(h0, h1))  # what the RCCL min-all-reduce produces
         for s in shards:
-            s.step_commit(red.data_ptr())
+            s.step_commit(red.ptr)
             e, b, _ = s.last_step()
             assert e == e_ref and np.array_equal(b, b_ref)
             assert np.array_equal(s.palette, ref.palette) and np.array_equal(s.palette_map, ref.palette_map)
@@ -334,7 +335,7 @@ def _golden():
 @pytest.mark.parametrize("case", _golden(), ids=lambda c: c["name"])
 def test_gpu_matches_golden(S, case):
     from snesimage_amd.synth import synth_image
-    import torch
+    from hipmem import DeviceArray
     g_ = case
     img = synth_image(g_["seed"], 256, g_["h"], g_["variant"])
     g = S.OptimizedImage(img, g_["count"], g_["size"], dither=g_["dither"], perceptual=g_["perceptual"], nes=g_["nes"])
@@ -348,13 +349,13 @@ def test_gpu_matches_golden(S, case):
     assert rel(g.error(), float.fromhex(g_["error_hex"])) < REL_ERR
     cand = S.random_candidates(1, 42, g_["ncand"])
     n = g_["ncand"]
-    d_c = torch.from_numpy(cand).cuda()
-    d_e = torch.zeros(n, dtype=torch.float64, device="cuda")
-    d_m = torch.zeros((n, g_["h"], 256), dtype=torch.uint8, device="cuda")
-    g.score_candidates_device(g_["slot"][0], g_["slot"][1], d_c.data_ptr(), n, d_e.data_ptr(), d_m.data_ptr())
+    d_c = DeviceArray.from_numpy(cand)
+    d_e = DeviceArray(n, np.float64, fill=0)
+    d_m = DeviceArray((n, g_["h"], 256), np.uint8, fill=0)
+    g.score_candidates_device(g_["slot"][0], g_["slot"][1], d_c.ptr, n, d_e.ptr, d_m.ptr)
     g.sync()
-    assert hashlib.sha256(d_m.cpu().numpy().tobytes()).hexdigest() == g_["cand_maps_sha"]
-    assert rel(d_e.cpu().numpy(), [float.fromhex(h) for h in g_["cand_errors_hex"]]) < REL_ERR
+    assert hashlib.sha256(d_m.numpy().tobytes()).hexdigest() == g_["cand_maps_sha"]
+    assert rel(d_e.numpy(), [float.fromhex(h) for h in g_["cand_errors_hex"]]) < REL_ERR
     err, best = g.step(2 if g_["nes"] else 0, g_["slot"][0], g_["slot"][1], 0, 1, 7)
     assert best.tolist() == g_["step_best"] and rel(err, float.fromhex(g_["step_error_hex"])) < REL_ERR
     assert hashlib.sha256(g.as_json().encode()).hexdigest() == g_["json_sha"]
