@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64) void k_sparse_h(SparseParams P) {
 // block = 256 threads = 256/W_s (candidate, channel) pairs; thread = one image column.
 // Checkpoint record g (0 <= g <= H/4 + 1) of B: recurrence state before group iteration g (steps 4g-4..4g-1)
 // and pooling sums of rows < 4g-4; record H/4+1 holds the final sums.
-__global__ __launch_bounds__(256) void k_sparse_v(SparseParams P) {
+__global__ __launch_bounds__(256, 3) void k_sparse_v(SparseParams P) {
     __shared__ float s_lut[3][256];
     __shared__ double red[256][6];
     __shared__ short s_gslot[256];
