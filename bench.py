@@ -145,7 +145,9 @@ def main():
         total = n_total * args.steps
         value = total / dt
         # dominant kernel of the launch group
-        dom = "k_vpass<scale0>" if tim["vpass0_ms"] >= tim["hpass0_ms"] else "k_hpass<scale0>"
+        sparse = args.config == "rgb" and os.environ.get("SNES_SPARSE", "1") != "0" and n_total // world >= 128
+        vname, hname = ("k_sparse_v", "k_sparse_h") if sparse else ("k_vpass_fast<scale0>", "k_hpass_fast<scale0>")
+        dom = vname if tim["vpass0_ms"] >= tim["hpass0_ms"] else hname
         dom_ms = max(tim["vpass0_ms"], tim["hpass0_ms"]) / max(1, tim["launches"])
         per_launch = tim["candidates"] / max(1, tim["launches"])
         achieved = ALGO_BYTES_PER_CANDIDATE * per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0

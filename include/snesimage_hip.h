@@ -52,7 +52,7 @@ void snesimage_destroy(snesimage_ctx *ctx);
 int32_t snesimage_set_stream(snesimage_ctx *ctx, void *hip_stream);
 /* Block until all work queued by this context has finished. */
 int32_t snesimage_sync(snesimage_ctx *ctx);
-/* Candidates scored per internal launch group (bounds the workspace); default 256. */
+/* Candidates scored per internal launch group (bounds the workspace); default 1024. */
 int32_t snesimage_set_chunk(snesimage_ctx *ctx, uint32_t chunk);
 
 int32_t snesimage_initialize_tiles(snesimage_ctx *ctx);     /* lib.rs:79-189  */

@@ -96,7 +96,7 @@ struct snesimage_ctx {
     Geom G{};
     BlurK K{};
     size_t npx = 0, src_floats = 0;
-    uint32_t chunk = 512, chunk_alloc = 0;
+    uint32_t chunk = 1024, chunk_alloc = 0;
 
     std::vector<uint8_t> h_orig; float h_eotf[256], h_lab_eotf[256];
 
