@@ -65,56 +65,64 @@ __device__ __forceinline__ uint32_t sparse_ci(uint32_t lo, uint32_t thr, uint32_
 }
 
 // ---- which groups does each candidate change? ---------------------------------------------------------
+// One wavefront per candidate (four candidates per block).  Each lane tests its share of the slot's
+// contested pixels and keeps a 64-bit mask of the 4-row groups it saw change; the wave ORs the masks
+// (and min-reduces x) with shuffles.  A scale has at most 64 groups, so its changed set is one 64-bit
+// word: scale s+1 is the pairwise OR of scale s, a group's slot is a popcount.  No LDS, no barriers.
+__device__ __forceinline__ unsigned long long pair_or_compress(unsigned long long m) { // bit i of result = bit 2i | bit 2i+1 of m
+    m = (m | (m >> 1)) & 0x5555555555555555ull;
+    m = (m | (m >> 1)) & 0x3333333333333333ull;
+    m = (m | (m >> 2)) & 0x0f0f0f0f0f0f0f0full;
+    m = (m | (m >> 4)) & 0x00ff00ff00ff00ffull;
+    m = (m | (m >> 8)) & 0x0000ffff0000ffffull;
+    m = (m | (m >> 16)) & 0x00000000ffffffffull;
+    return m;
+}
 __global__ __launch_bounds__(256) void k_sparse_scan(SparseParams P) {
-    __shared__ unsigned int s_mask[8];
-    __shared__ int s_xmin, s_won;
-    __shared__ int s_flag[64];
-    __shared__ int s_base;
     const Geom &G = P.G;
-    const int t = threadIdx.x;
-    const int k = P.is_base ? P.base : P.k0 + (int)blockIdx.x;
-    if (t < 8) s_mask[t] = P.is_base ? 0xffffffffu : 0u;
-    if (t == 0) { s_xmin = P.is_base ? 0 : G.W; s_won = 0; }
-    __syncthreads();
-    if (!P.is_base) {
+    const int lane = threadIdx.x & 63;
+    const int wi = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (!P.is_base && wi >= P.ncand) return;
+    if (P.is_base && wi > 0) return;
+    const int k = P.is_base ? P.base : P.k0 + wi;
+    unsigned long long mask = 0ull; int xmin = G.W, won = 0;
+    if (P.is_base) { mask = ~0ull; xmin = 0; }
+    else {
         const uint32_t crgb = __float_as_uint(P.cand_tab[8 * (size_t)k + 6]);
         const int n = *P.plist_count;
-        for (int i = t; i < n; i += 256) {
+        for (int i = lane; i < n; i += 64) {
             const uint4 e = P.plist[i];
             if (red_mean_key(crgb, e.y) < e.z) {
                 const int x = (int)(e.x % (unsigned)G.W), y = (int)(e.x / (unsigned)G.W);
-                atomicOr(&s_mask[y >> 5], 1u << (y & 31));
-                atomicMin(&s_xmin, x);
-                atomicAdd(&s_won, 1);
+                mask |= 1ull << (y >> 2);
+                xmin = min(xmin, x);
+                won++;
             }
         }
-        __syncthreads();
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mask |= __shfl_xor(mask, o);
+            xmin = min(xmin, __shfl_xor(xmin, o));
+            won += __shfl_xor(won, o);
+        }
     }
     CandMeta *M = P.meta + k;
-    if (t == 0) { M->xmin = s_xmin; M->won = s_won; }
+    if (lane == 0) { M->xmin = xmin; M->won = won; }
+    unsigned long long m = mask; // scale 0: 64 groups (H = 256)
     for (int s = 0; s < G.nscales; s++) {
         const int NG = G.sh[s] >> 2;
-        int flag = 0;
-        if (t < NG) { // group t of scale s covers scale-0 rows [4t << s, (4t+4) << s)
-            const int lo = (4 * t) << s, len = 4 << s;
-            for (int w = lo >> 5; w <= (lo + len - 1) >> 5; w++) {
-                const int b0 = max(lo, w << 5) & 31, b1 = min(lo + len, (w + 1) << 5) - (w << 5); // bits [b0, b1) of word w
-                const unsigned int m = (b1 - b0 >= 32) ? 0xffffffffu : (((1u << (b1 - b0)) - 1u) << b0);
-                flag |= (s_mask[w] & m) != 0u;
-            }
+        const int total = __popcll(m);
+        if (lane < NG) {
+            const int flag = (int)((m >> lane) & 1ull);
+            const int below = __popcll(m & ((1ull << lane) - 1ull));
+            M->gslot[P.S.goff[s] + lane] = flag ? (short)below : (short)-1;
+            if (flag) M->glist[P.S.goff[s] + below] = (unsigned char)lane;
         }
-        if (t < 64) s_flag[t] = flag;
-        __syncthreads();
-        int below = 0, total = 0;
-        for (int i = 0; i < NG; i++) { const int f = s_flag[i]; total += f; if (i < t) below += f; }
-        if (t < NG) {
-            M->gslot[P.S.goff[s] + t] = flag ? (short)below : (short)-1;
-            if (flag) M->glist[P.S.goff[s] + below] = (unsigned char)t;
-        }
-        if (t == 0) { M->ngroups[s] = total; s_base = total ? atomicAdd(&P.item_count[s], total * 3) : 0; }
-        __syncthreads();
-        for (int i = t; i < total * 3; i += 256) P.items[(size_t)s * P.item_stride + s_base + i] = (unsigned int)k * 256u + (unsigned int)(i / 3) * 4u + (unsigned int)(i % 3);
-        __syncthreads();
+        int base = 0;
+        if (lane == 0) { M->ngroups[s] = total; base = total ? atomicAdd(&P.item_count[s], total * 3) : 0; }
+        base = __shfl(base, 0);
+        for (int i = lane; i < total * 3; i += 64) P.items[(size_t)s * P.item_stride + base + i] = (unsigned int)k * 256u + (unsigned int)(i / 3) * 4u + (unsigned int)(i % 3);
+        m = pair_or_compress(m);
     }
 }
 
@@ -183,6 +191,74 @@ __global__ __launch_bounds__(256) void k_sparse_down(SparseParams P, int only_sc
         }
         __syncthreads(); // the rows written above are read by this block at the next scale
     }
+}
+
+// ---- B's downscale chain in one launch: one block = one 32x32 block of scale-0 pixels -> 16x16, 8x8, ... 1x1 ----
+// (same arithmetic as k_sparse_down / k_downscale_chain; only the store addresses follow B's group-major layouts)
+__device__ __forceinline__ void base_store(const SparseParams &P, float *mine, int s, int X, int Y, const float *lin, bool keep_lin) {
+    const int Ws = P.G.sw[s];
+    const int g = Y >> 2, r = Y & 3;
+    float Xc, Yc, Bc;
+    linear_to_positive_xyb(lin[0], lin[1], lin[2], Xc, Yc, Bc);
+    const float xyb[3] = {Xc, Yc, Bc};
+    float *ol = mine + P.S.off_lin[s] + (size_t)g * 12 * Ws;
+    float *oc = mine + P.S.off_xybC[s] + (size_t)g * 12 * Ws, *orr = mine + P.S.off_xybR[s] + (size_t)g * 12 * Ws;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        if (keep_lin) ol[(size_t)(c * 4 + r) * Ws + X] = lin[c];
+        oc[(size_t)c * 4 * Ws + (size_t)(X >> 2) * 16 + r * 4 + (X & 3)] = xyb[c];
+        orr[(size_t)c * 4 * Ws + (size_t)X * 4 + r] = xyb[c];
+    }
+}
+__global__ __launch_bounds__(256) void k_base_down(SparseParams P) {
+    __shared__ float s_lin[256 * 3];
+    __shared__ float l1[3][16][17], l2[3][8][9], l3[3][4][5], l4[3][2][3];
+    const Geom &G = P.G;
+    const int t = threadIdx.x;
+    const int bx = blockIdx.x % (G.W / 32), by = blockIdx.x / (G.W / 32);
+    for (int i = t; i < (P.ncol + 2) * 3; i += 256) s_lin[i] = P.pal_lin[i];
+    __syncthreads();
+    float *mine = P.store + (size_t)P.base * P.S.cand_stride;
+    {
+        const int lx = t & 15, ly = t >> 4;
+        const int X1 = bx * 16 + lx, Y1 = by * 16 + ly;
+        float sum[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int iy = 0; iy < 2; iy++)
+#pragma unroll
+            for (int ix = 0; ix < 2; ix++) {
+                const uint32_t ci = (uint32_t)P.pack[(size_t)(Y1 * 2 + iy) * G.W + X1 * 2 + ix] >> 24;
+                sum[0] += s_lin[3 * ci]; sum[1] += s_lin[3 * ci + 1]; sum[2] += s_lin[3 * ci + 2];
+            }
+        const float v[3] = {sum[0] * 0.25f, sum[1] * 0.25f, sum[2] * 0.25f};
+        l1[0][ly][lx] = v[0]; l1[1][ly][lx] = v[1]; l1[2][ly][lx] = v[2];
+        base_store(P, mine, 1, X1, Y1, v, G.nscales > 2);
+    }
+    __syncthreads();
+#define SNES_BASE_LEVEL(S, SRC, DST, DIM)                                                              \
+    if (G.nscales > S) {                                                                               \
+        if (t < DIM * DIM) {                                                                           \
+            const int lx = t % DIM, ly = t / DIM;                                                      \
+            float v[3];                                                                                \
+            for (int c = 0; c < 3; c++) {                                                              \
+                float sum = 0.0f;                                                                      \
+                sum += SRC[c][2 * ly][2 * lx]; sum += SRC[c][2 * ly][2 * lx + 1];                      \
+                sum += SRC[c][2 * ly + 1][2 * lx]; sum += SRC[c][2 * ly + 1][2 * lx + 1];              \
+                v[c] = sum * 0.25f; DST[c][ly][lx] = v[c];                                             \
+            }                                                                                          \
+            base_store(P, mine, S, bx * DIM + lx, by * DIM + ly, v, G.nscales > S + 1);                \
+        }                                                                                              \
+        __syncthreads();                                                                               \
+    }
+    SNES_BASE_LEVEL(2, l1, l2, 8)
+    SNES_BASE_LEVEL(3, l2, l3, 4)
+    SNES_BASE_LEVEL(4, l3, l4, 2)
+    if (G.nscales > 5 && t == 0) {
+        float v[3];
+        for (int c = 0; c < 3; c++) { float sum = 0.0f; sum += l4[c][0][0]; sum += l4[c][0][1]; sum += l4[c][1][0]; sum += l4[c][1][1]; v[c] = sum * 0.25f; }
+        base_store(P, mine, 5, bx, by, v, false);
+    }
+#undef SNES_BASE_LEVEL
 }
 
 // recurrence steps, identical to kernels_fast.hpp
