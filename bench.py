@@ -93,9 +93,11 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("SNES_BENCH_FORCE_DIST") == "1"  # rehearse the RCCL path with a single rank
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     sub_count, sub_size = 8, 15
     flags = {"rgb": 0, "perceptual": S.PERCEPTUAL, "dither": S.DITHER}[args.config]
@@ -172,7 +174,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(img, sub_count, sub_size, flags, tile_palettes, palette)
         print(json.dumps(out), flush=True)
     image.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

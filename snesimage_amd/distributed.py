@@ -49,7 +49,7 @@ def sharded_step(scorer, method, palette, index, channel, seed, step_id, n_total
     else:
         rank, world = 0, 1
     errors = scorer.begin(method, palette, index, channel, seed, step_id, n_total, rank, world)
-    if world > 1:
+    if world > 1 or (dist.is_available() and dist.is_initialized()):
         dist.all_reduce(errors, op=dist.ReduceOp.MIN, group=group)
     scorer.commit(errors)
     return errors
