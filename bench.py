@@ -69,7 +69,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1024, help="candidates per step per GPU (weak) or in total (strong)")
+    ap.add_argument("--batch", type=int, default=4096,
+                    help="candidates per optimizer call per GPU (weak) or in total (strong); the reference draws 64 (lib.rs:205)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--config", choices=["rgb", "perceptual", "dither"], default="rgb")
     ap.add_argument("--chunk", type=int, default=0, help="candidates per launch group (0 = library default)")

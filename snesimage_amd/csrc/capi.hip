@@ -408,7 +408,7 @@ int32_t sparse_base_pass(snesimage_ctx *c) {
         SparseParams P = sparse_params(c, c->nlanes); // B has its own item list and counters
         P.is_base = 1; P.ncand = 1; P.k0 = P.base;
         HIPCHK(hipMemsetAsync(P.item_count, 0, sizeof(int) * kMaxScales, c->stream));
-        hipLaunchKernelGGL(k_sparse_scan, dim3(1), dim3(256), 0, c->stream, P);
+        hipLaunchKernelGGL(k_sparse_scan, dim3(1), dim3(1024), 0, c->stream, P);
         hipLaunchKernelGGL(k_base_down, dim3((unsigned)((G.W / 32) * (G.H / 32))), dim3(256), 0, c->stream, P); // B: every row of every scale
         // B's H and V passes are long single-image sweeps (latency-bound); they run on their own stream beside the
         // candidates' scan / downscale / H pass, which only need B's linear-RGB rows.  The candidates' V pass waits for them.
@@ -432,7 +432,7 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     if (c->timing) { for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&tr.ev[i])); HIPCHK(hipEventRecord(tr.ev[0], stream)); }
     hipLaunchKernelGGL(k_candidate_tables, dim3((nc + 63) / 64), dim3(64), 0, stream, d_rgb5, (int)nc, c->d_eotf, sp.cand_tab + 8 * (size_t)P.k0);
     HIPCHK(hipMemsetAsync(P.item_count, 0, sizeof(int) * kMaxScales, stream));
-    hipLaunchKernelGGL(k_sparse_scan, dim3((nc + 3) / 4), dim3(256), 0, stream, P);
+    hipLaunchKernelGGL(k_sparse_scan, dim3((nc + 15) / 16), dim3(1024), 0, stream, P);
     hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P, 0);
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[1], stream));
     { size_t gx = ((size_t)nc * (G.sh[0] / 4) * 3 + 15) / 16; if (gx > 2048) gx = 2048; // grid-stride over the item quads

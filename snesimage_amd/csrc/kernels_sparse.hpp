@@ -78,25 +78,39 @@ __device__ __forceinline__ unsigned long long pair_or_compress(unsigned long lon
     m = (m | (m >> 16)) & 0x00000000ffffffffull;
     return m;
 }
-__global__ __launch_bounds__(256) void k_sparse_scan(SparseParams P) {
+constexpr int kScanTile = 6144; // contested pixels staged in LDS per pass (the BASELINE slot has ~6.8 k)
+__global__ __launch_bounds__(1024) void k_sparse_scan(SparseParams P) {
+    // 16 waves = 16 candidates per block share one LDS copy of the slot's contested-pixel list
+    __shared__ uint32_t s_rgb[kScanTile], s_thr[kScanTile];
+    __shared__ unsigned short s_px[kScanTile]; // x | (y>>2) << 8 would lose x precision: keep x (8 bit) and group (6 bit)
     const Geom &G = P.G;
     const int lane = threadIdx.x & 63;
-    const int wi = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (!P.is_base && wi >= P.ncand) return;
-    if (P.is_base && wi > 0) return;
-    const int k = P.is_base ? P.base : P.k0 + wi;
+    const int wi = (int)blockIdx.x * 16 + (threadIdx.x >> 6);
+    const bool live = P.is_base ? (wi == 0) : (wi < P.ncand);
+    const int k = P.is_base ? P.base : P.k0 + (live ? wi : 0);
     unsigned long long mask = 0ull; int xmin = G.W, won = 0;
     if (P.is_base) { mask = ~0ull; xmin = 0; }
     else {
         const uint32_t crgb = __float_as_uint(P.cand_tab[8 * (size_t)k + 6]);
         const int n = *P.plist_count;
-        for (int i = lane; i < n; i += 64) {
-            const uint4 e = P.plist[i];
-            if (red_mean_key(crgb, e.y) < e.z) {
-                const int x = (int)(e.x % (unsigned)G.W), y = (int)(e.x / (unsigned)G.W);
-                mask |= 1ull << (y >> 2);
-                xmin = min(xmin, x);
-                won++;
+        for (int t0 = 0; t0 < n; t0 += kScanTile) {
+            const int nt = min(kScanTile, n - t0);
+            __syncthreads();
+            for (int i = threadIdx.x; i < nt; i += 1024) {
+                const uint4 e = P.plist[t0 + i];
+                s_rgb[i] = e.y; s_thr[i] = e.z;
+                s_px[i] = (unsigned short)((e.x & (unsigned)(G.W - 1)) | ((e.x / (unsigned)G.W) >> 2) << 8);
+            }
+            __syncthreads();
+            if (live) {
+                for (int i = lane; i < nt; i += 64) {
+                    if (red_mean_key(crgb, s_rgb[i]) < s_thr[i]) {
+                        const int px = s_px[i];
+                        mask |= 1ull << (px >> 8);
+                        xmin = min(xmin, px & 255);
+                        won++;
+                    }
+                }
             }
         }
 #pragma unroll
@@ -106,9 +120,27 @@ __global__ __launch_bounds__(256) void k_sparse_scan(SparseParams P) {
             won += __shfl_xor(won, o);
         }
     }
+    // Work-item slots: one returning atomic per block and scale (a single counter word serialises at ~90 atomics/us,
+    // so one per candidate would cost more than the scan itself); the block's 16 waves take consecutive ranges.
+    __shared__ int s_tot[16][kMaxScales], s_off[16][kMaxScales];
+    const int w = threadIdx.x >> 6;
+    unsigned long long m = live ? mask : 0ull;
+    if (lane == 0) {
+        unsigned long long mm = m;
+        for (int s = 0; s < G.nscales; s++) { s_tot[w][s] = 3 * __popcll(mm); mm = pair_or_compress(mm); }
+    }
+    __syncthreads();
+    if (threadIdx.x < G.nscales) {
+        const int s = threadIdx.x;
+        int sum = 0;
+        for (int i = 0; i < 16; i++) { s_off[i][s] = sum; sum += s_tot[i][s]; }
+        const int base = sum ? atomicAdd(&P.item_count[s], sum) : 0;
+        for (int i = 0; i < 16; i++) s_off[i][s] += base;
+    }
+    __syncthreads();
+    if (!live) return;
     CandMeta *M = P.meta + k;
     if (lane == 0) { M->xmin = xmin; M->won = won; }
-    unsigned long long m = mask; // scale 0: 64 groups (H = 256)
     for (int s = 0; s < G.nscales; s++) {
         const int NG = G.sh[s] >> 2;
         const int total = __popcll(m);
@@ -118,9 +150,8 @@ __global__ __launch_bounds__(256) void k_sparse_scan(SparseParams P) {
             M->gslot[P.S.goff[s] + lane] = flag ? (short)below : (short)-1;
             if (flag) M->glist[P.S.goff[s] + below] = (unsigned char)lane;
         }
-        int base = 0;
-        if (lane == 0) { M->ngroups[s] = total; base = total ? atomicAdd(&P.item_count[s], total * 3) : 0; }
-        base = __shfl(base, 0);
+        if (lane == 0) M->ngroups[s] = total;
+        const int base = s_off[w][s];
         for (int i = lane; i < total * 3; i += 64) P.items[(size_t)s * P.item_stride + base + i] = (unsigned int)k * 256u + (unsigned int)(i / 3) * 4u + (unsigned int)(i % 3);
         m = pair_or_compress(m);
     }
