@@ -282,23 +282,56 @@ __global__ __launch_bounds__(256) void k_km_update(KmParams P) {
     const int t = threadIdx.x;
     __shared__ double s_obj;
     __shared__ int s_stop;
+    // The summation orders are the reference's (point order), so each sum is one sequential chain; what can be
+    // parallel is the memory traffic: the block stages tiles of (cost, assignment, point) in LDS and the chain
+    // threads read them there (the same LDS address for every cluster thread: a broadcast).
+    constexpr int TILE = 1024;
+    __shared__ double s_cost[TILE];
+    __shared__ uint32_t s_asg[TILE];
+    __shared__ double s_pts[TILE * 3];
     const uint32_t *assign = P.assign + P.off[prob];
-    double c0 = 0.0, c1 = 0.0, c2 = 0.0; uint32_t cnt = 0;
+    const double *cost = P.cost + P.off[prob];
+    const double *pts = P.pts + 3 * P.off[prob];
+    double o = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0; uint32_t cnt = 0;
+    const int i = t - 1; // cluster of threads 1..k
+    for (int p0 = 0; p0 < n; p0 += TILE) {
+        const int nt = min(TILE, n - p0);
+        __syncthreads();
+        const int ntp = (nt + 7) & ~7; // padded to the 8-wide register batches below: +0.0 terms, no-cluster assignments
+        for (int j = t; j < ntp; j += 256) { s_cost[j] = j < nt ? cost[p0 + j] : 0.0; s_asg[j] = j < nt ? assign[p0 + j] : 0xffffffffu; }
+        for (int j = t; j < ntp * 3; j += 256) s_pts[j] = j < nt * 3 ? pts[3 * (size_t)p0 + j] : 0.0;
+        __syncthreads();
+        if (t == 0) {
+            for (int j0 = 0; j0 < ntp; j0 += 8) { // eight LDS reads in flight, then the ordered adds
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = s_cost[j0 + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) o = o + v[u];
+            }
+        } else if (t <= P.k) {
+            // branch-free: a non-member adds +0.0, which leaves the running sum bit-identical (it is never -0.0)
+            for (int j0 = 0; j0 < ntp; j0 += 8) {
+                uint32_t a[8]; double x[8], y[8], z[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { a[u] = s_asg[j0 + u]; x[u] = s_pts[3 * (j0 + u)]; y[u] = s_pts[3 * (j0 + u) + 1]; z[u] = s_pts[3 * (j0 + u) + 2]; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const bool mine = a[u] == (uint32_t)i;
+                    s0 += mine ? x[u] : 0.0; s1 += mine ? y[u] : 0.0; s2 += mine ? z[u] : 0.0;
+                    cnt += mine ? 1u : 0u;
+                }
+            }
+        }
+    }
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
     if (t == 0) {
-        const double *cost = P.cost + P.off[prob];
-        double o = 0.0;
-        for (int p = 0; p < n; p++) o = o + cost[p];
         s_obj = o;
         int stop = 0;
         if (!P.first && fabs(o - P.objective[prob]) < 1e-6) stop = 1; // converged: keep the centres of this assignment
         if (P.last) stop = 1;                                            // iteration cap (100): no further update_centres
         s_stop = stop;
     } else if (t <= P.k) {
-        const int i = t - 1;
-        const double *pts = P.pts + 3 * P.off[prob];
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-        for (int p = 0; p < n; p++)
-            if (assign[p] == (uint32_t)i) { s0 += pts[3 * p]; s1 += pts[3 * p + 1]; s2 += pts[3 * p + 2]; cnt++; }
         const double sc = 1.0 / (double)cnt; // empty cluster -> inf -> NaN centre, as in the reference
         c0 = s0 * sc; c1 = s1 * sc; c2 = s2 * sc;
     }
