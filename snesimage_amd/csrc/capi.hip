@@ -121,7 +121,7 @@ struct snesimage_ctx {
     struct Sparse {
         bool enabled = false; uint32_t min_n = 128; uint32_t cap = 0; // cap = candidates per lane the arrays were sized for
         SparseGeom S{};
-        float *store = nullptr, *cand_tab = nullptr, *ckf = nullptr; double *cka = nullptr, *part = nullptr;
+        float *store = nullptr, *cand_tab = nullptr, *cand_lab = nullptr, *ckf = nullptr; uint32_t *bitmap = nullptr; double *cka = nullptr, *part = nullptr;
         CandMeta *meta = nullptr; unsigned int *items = nullptr; int *item_count = nullptr; long long item_stride = 0;
         uint4 *plist = nullptr; int *plist_count = nullptr; bool plist_valid = false;
         hipStream_t base_stream = nullptr; hipEvent_t ev_base_in = nullptr, ev_base_done = nullptr; // B's H and V passes run beside the candidates' scan/down/H
@@ -366,6 +366,11 @@ int32_t sparse_alloc(snesimage_ctx *c) {
     sp.item_stride = (long long)c->chunk * (G.sh[0] / 4) * 3;
     HIPCHK(hipMalloc(&sp.store, sizeof(float) * (size_t)S.cand_stride * ncap));
     HIPCHK(hipMalloc(&sp.cand_tab, sizeof(float) * 8 * ncap));
+    if (c->perceptual) {
+        dfree(sp.cand_lab); dfree(sp.bitmap);
+        HIPCHK(hipMalloc(&sp.cand_lab, sizeof(float) * 3 * ncap));
+        HIPCHK(hipMalloc(&sp.bitmap, sizeof(uint32_t) * (c->npx / 32) * ncap));
+    }
     HIPCHK(hipMalloc(&sp.ckf, sizeof(float) * (size_t)okf));
     HIPCHK(hipMalloc(&sp.cka, sizeof(double) * (size_t)oka));
     HIPCHK(hipMalloc(&sp.part, sizeof(double) * ncap * kMaxScales * 18));
@@ -391,6 +396,7 @@ SparseParams sparse_params(snesimage_ctx *c, uint32_t lane) {
     P.G = c->G; P.S = sp.S; P.K = c->K; P.ncol = c->ncol; P.base = (int)(c->nlanes * c->chunk);
     P.pack = c->d_pack; P.packC4 = c->d_packC4; P.packR4 = c->d_packR4; P.plist = sp.plist; P.plist_count = sp.plist_count;
     P.pal_lin = c->d_pal_lin; P.pal_xyb = c->d_pal_xyb; P.cand_tab = sp.cand_tab;
+    P.perceptual = c->perceptual ? 1 : 0; P.labpx = c->d_labpx; P.cand_lab = sp.cand_lab; P.bitmap = sp.bitmap;
     P.img1C4 = c->d_img1C4; P.img1R4 = c->d_img1R4; P.mu1R4 = c->d_mu1R4; P.s11R4 = c->d_s11R4;
     P.store = sp.store; P.meta = sp.meta;
     P.items = sp.items + (size_t)lane * sp.item_stride * kMaxScales; P.item_count = sp.item_count + (size_t)lane * kMaxScales; P.item_stride = sp.item_stride; // lane == nlanes: B
@@ -432,7 +438,11 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     if (c->timing) { for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&tr.ev[i])); HIPCHK(hipEventRecord(tr.ev[0], stream)); }
     hipLaunchKernelGGL(k_candidate_tables, dim3((nc + 63) / 64), dim3(64), 0, stream, d_rgb5, (int)nc, c->d_eotf, sp.cand_tab + 8 * (size_t)P.k0);
     HIPCHK(hipMemsetAsync(P.item_count, 0, sizeof(int) * kMaxScales, stream));
-    hipLaunchKernelGGL(k_sparse_scan, dim3((nc + 15) / 16), dim3(1024), 0, stream, P);
+    if (c->perceptual) {
+        hipLaunchKernelGGL(k_candidate_lab, dim3((nc + 63) / 64), dim3(64), 0, stream, sp.cand_tab + 8 * (size_t)P.k0, (int)nc, c->d_lab_eotf, sp.cand_lab + 3 * (size_t)P.k0);
+        HIPCHK(hipMemsetAsync(sp.bitmap + (size_t)P.k0 * (c->npx / 32), 0, sizeof(uint32_t) * (c->npx / 32) * nc, stream));
+        hipLaunchKernelGGL(k_sparse_scan_lab, dim3((nc + 3) / 4), dim3(256), 0, stream, P);
+    } else hipLaunchKernelGGL(k_sparse_scan, dim3((nc + 15) / 16), dim3(1024), 0, stream, P);
     hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P, 0);
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[1], stream));
     { size_t gx = ((size_t)nc * (G.sh[0] / 4) * 3 + 15) / 16; if (gx > 2048) gx = 2048; // grid-stride over the item quads
@@ -601,7 +611,7 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     c->K = make_blur_constants();
     if (const char *e = getenv("SNES_CHUNK")) { int v = atoi(e); if (v > 0) c->chunk = (uint32_t)v; }
     if (const char *e = getenv("SNES_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->nlanes = (uint32_t)v; }
-    c->sp.enabled = (h == 256) && !c->dither && !c->perceptual; // the row-sparse path covers the RGB / no-dither remap at the full size
+    c->sp.enabled = (h == 256) && !c->dither; // the group-sparse path covers the no-dither remap (RGB keys or CIEDE2000) at the full size
     if (const char *e = getenv("SNES_SPARSE")) c->sp.enabled = c->sp.enabled && atoi(e) != 0;
     if (const char *e = getenv("SNES_SPARSE_MIN")) { int v = atoi(e); if (v >= 1) c->sp.min_n = (uint32_t)v; }
     Geom &G = c->G;
@@ -688,7 +698,7 @@ void snesimage_destroy(snesimage_ctx *c) {
     dfree(c->d_cand); dfree(c->d_cand_sel); dfree(c->d_errs); dfree(c->d_errs_sel); dfree(c->d_inc_err); dfree(c->d_last); dfree(c->d_scratch_err); dfree(c->d_dummy_cand);
     for (auto &L : c->extra) { if (L.stream) (void)hipStreamSynchronize(L.stream); dfree(L.d_work); dfree(L.d_cand_tab); dfree(L.d_cand_lab); dfree(L.d_part); dfree(L.d_maps); dfree(L.d_mapsT); if (L.done) (void)hipEventDestroy(L.done); if (L.stream) (void)hipStreamDestroy(L.stream); }
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
-    { auto &q = c->sp; if (q.base_stream) { (void)hipStreamSynchronize(q.base_stream); (void)hipStreamDestroy(q.base_stream); (void)hipEventDestroy(q.ev_base_in); (void)hipEventDestroy(q.ev_base_done); } dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.plist_count); }
+    { auto &q = c->sp; if (q.base_stream) { (void)hipStreamSynchronize(q.base_stream); (void)hipStreamDestroy(q.base_stream); (void)hipEventDestroy(q.ev_base_in); (void)hipEventDestroy(q.ev_base_done); } dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.plist_count); dfree(q.cand_lab); dfree(q.bitmap); }
     kmeans_free(c->km);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;

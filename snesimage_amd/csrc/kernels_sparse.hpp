@@ -54,6 +54,9 @@ struct SparseParams {
     const unsigned long long *pack, *packC4, *packR4;
     const uint4 *plist; const int *plist_count; // contested pixels of the slot: {px, rgb, thr, 0}
     const float *pal_lin, *pal_xyb, *cand_tab;
+    // --perceptual-palettes: the win test is CIEDE2000 (f32), too dear to repeat per stage: k_sparse_scan_lab evaluates it once
+    // per contested pixel and records the won pixels in a per-candidate bitmap (W*H bits) that the other stages consult
+    int perceptual; const float *labpx, *cand_lab; uint32_t *bitmap;
     const float *img1C4, *img1R4, *mu1R4, *s11R4; // source arrays in the blocked layouts, + G.src_off[s]
     float *store; CandMeta *meta;
     unsigned int *items; int *item_count; long long item_stride; // per scale: items[s*item_stride + i] = cand*256 + slot*4 + ch
@@ -62,6 +65,81 @@ struct SparseParams {
 
 __device__ __forceinline__ uint32_t sparse_ci(uint32_t lo, uint32_t thr, uint32_t crgb, uint32_t ncol) {
     return red_mean_key(crgb, lo & 0x00ffffffu) < thr ? ncol : (lo >> 24); // B passes crgb with thr ignored: see callers
+}
+
+__device__ __forceinline__ unsigned long long pair_or_compress(unsigned long long m);
+__device__ __forceinline__ uint32_t won_bit(const uint32_t *bm, int px) { return (bm[px >> 5] >> (px & 31)) & 1u; }
+
+// ---- perceptual scan: CIEDE2000 win test per contested pixel, one wave per candidate ------------------------
+__global__ __launch_bounds__(256) void k_sparse_scan_lab(SparseParams P) {
+    const Geom &G = P.G;
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int wi = (int)blockIdx.x * 4 + w;
+    const bool live = wi < P.ncand;
+    const int k = P.k0 + (live ? wi : 0);
+    unsigned long long mask = 0ull; int xmin = G.W, won = 0;
+    if (live) {
+        Lab cl; cl.l = P.cand_lab[3 * (size_t)k]; cl.a = P.cand_lab[3 * (size_t)k + 1]; cl.b = P.cand_lab[3 * (size_t)k + 2];
+        uint32_t *bm = P.bitmap + (size_t)k * (G.W * G.H / 32);
+        const int n = *P.plist_count;
+        for (int i = lane; i < n; i += 64) {
+            const uint4 e = P.plist[i];
+            const uint32_t thr = e.z;
+            bool win;
+            if (thr == 0xffffffffu) win = true;
+            else {
+                Lab t; t.l = P.labpx[3 * (size_t)e.x]; t.a = P.labpx[3 * (size_t)e.x + 1]; t.b = P.labpx[3 * (size_t)e.x + 2];
+                const float d = ciede2000(cl, t), bd = __uint_as_float(thr & 0x7fffffffu);
+                win = (d < bd) || ((thr & 0x80000000u) && d == bd); // strict <, ties to the lower index (lib.rs:788-791)
+            }
+            if (win) {
+                const int x = (int)(e.x & (unsigned)(G.W - 1)), y = (int)(e.x / (unsigned)G.W);
+                atomicOr(&bm[e.x >> 5], 1u << (e.x & 31));
+                mask |= 1ull << (y >> 2);
+                xmin = min(xmin, x);
+                won++;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mask |= __shfl_xor(mask, o);
+            xmin = min(xmin, __shfl_xor(xmin, o));
+            won += __shfl_xor(won, o);
+        }
+    }
+    __shared__ int s_tot[4][kMaxScales], s_off[4][kMaxScales];
+    unsigned long long m = live ? mask : 0ull;
+    if (lane == 0) {
+        unsigned long long mm = m;
+        for (int s = 0; s < G.nscales; s++) { s_tot[w][s] = 3 * __popcll(mm); mm = pair_or_compress(mm); }
+    }
+    __syncthreads();
+    if (threadIdx.x < G.nscales) {
+        const int s = threadIdx.x;
+        int sum = 0;
+        for (int i = 0; i < 4; i++) { s_off[i][s] = sum; sum += s_tot[i][s]; }
+        const int base = sum ? atomicAdd(&P.item_count[s], sum) : 0;
+        for (int i = 0; i < 4; i++) s_off[i][s] += base;
+    }
+    __syncthreads();
+    if (!live) return;
+    CandMeta *M = P.meta + k;
+    if (lane == 0) { M->xmin = xmin; M->won = won; }
+    for (int s = 0; s < G.nscales; s++) {
+        const int NG = G.sh[s] >> 2;
+        const int total = __popcll(m);
+        if (lane < NG) {
+            const int flag = (int)((m >> lane) & 1ull);
+            const int below = __popcll(m & ((1ull << lane) - 1ull));
+            M->gslot[P.S.goff[s] + lane] = flag ? (short)below : (short)-1;
+            if (flag) M->glist[P.S.goff[s] + below] = (unsigned char)lane;
+        }
+        if (lane == 0) M->ngroups[s] = total;
+        const int base = s_off[w][s];
+        for (int i = lane; i < total * 3; i += 64) P.items[(size_t)s * P.item_stride + base + i] = (unsigned int)k * 256u + (unsigned int)(i / 3) * 4u + (unsigned int)(i % 3);
+        m = pair_or_compress(m);
+    }
 }
 
 // ---- which groups does each candidate change? ---------------------------------------------------------
@@ -191,7 +269,10 @@ __global__ __launch_bounds__(256) void k_sparse_down(SparseParams P, int only_sc
 #pragma unroll
                     for (int ix = 0; ix < 2; ix++) {
                         const unsigned long long w = P.pack[(size_t)(2 * y + iy) * G.W + 2 * x + ix];
-                        const uint32_t ci = is_base ? ((uint32_t)w >> 24) : sparse_ci((uint32_t)w, (uint32_t)(w >> 32), crgb, (uint32_t)P.ncol);
+                        const int px0 = (2 * y + iy) * G.W + 2 * x + ix;
+                        const uint32_t ci = is_base ? ((uint32_t)w >> 24)
+                                          : (P.perceptual ? (won_bit(P.bitmap + (size_t)k * (G.W * G.H / 32), px0) ? (uint32_t)P.ncol : ((uint32_t)w >> 24))
+                                                          : sparse_ci((uint32_t)w, (uint32_t)(w >> 32), crgb, (uint32_t)P.ncol));
                         sum[0] += s_lin[3 * ci]; sum[1] += s_lin[3 * ci + 1]; sum[2] += s_lin[3 * ci + 2];
                     }
                 v[0] = sum[0] * 0.25f; v[1] = sum[1] * 0.25f; v[2] = sum[2] * 0.25f;
@@ -370,8 +451,16 @@ __global__ __launch_bounds__(64) void k_sparse_h(SparseParams P) {
                 if (S0) { n_pa = pk[(size_t)(g + 1) * H * 2]; n_pb = pk[(size_t)(g + 1) * H * 2 + 1]; } else r2[un] = in2[(size_t)(g + 1) * 4];
             } else { r1[un] = make_float4(0.f, 0.f, 0.f, 0.f); r2[un] = r1[un]; n_pa = make_uint4(0, 0, 0, 0); n_pb = n_pa; }
             if (S0 && g < G4) {
-                const uint32_t c0 = sparse_ci(c_pa.x, c_pa.y & never, crgb, (uint32_t)P.ncol), c1 = sparse_ci(c_pa.z, c_pa.w & never, crgb, (uint32_t)P.ncol);
-                const uint32_t c2 = sparse_ci(c_pb.x, c_pb.y & never, crgb, (uint32_t)P.ncol), c3 = sparse_ci(c_pb.z, c_pb.w & never, crgb, (uint32_t)P.ncol);
+                uint32_t c0, c1, c2, c3;
+                if (P.perceptual && !is_base) { // four consecutive pixels of row y: four consecutive bits of one bitmap word
+                    const int px0 = y * W + (g << 2);
+                    const uint32_t b4 = (P.bitmap[(size_t)k * (G.W * G.H / 32) + (px0 >> 5)] >> (px0 & 31)) & 0xfu;
+                    c0 = (b4 & 1u) ? (uint32_t)P.ncol : (c_pa.x >> 24); c1 = (b4 & 2u) ? (uint32_t)P.ncol : (c_pa.z >> 24);
+                    c2 = (b4 & 4u) ? (uint32_t)P.ncol : (c_pb.x >> 24); c3 = (b4 & 8u) ? (uint32_t)P.ncol : (c_pb.z >> 24);
+                } else {
+                    c0 = sparse_ci(c_pa.x, c_pa.y & never, crgb, (uint32_t)P.ncol); c1 = sparse_ci(c_pa.z, c_pa.w & never, crgb, (uint32_t)P.ncol);
+                    c2 = sparse_ci(c_pb.x, c_pb.y & never, crgb, (uint32_t)P.ncol); c3 = sparse_ci(c_pb.z, c_pb.w & never, crgb, (uint32_t)P.ncol);
+                }
                 r2[u].x = c0 == (uint32_t)P.ncol ? cand_v : s_lut[ch][c0]; r2[u].y = c1 == (uint32_t)P.ncol ? cand_v : s_lut[ch][c1];
                 r2[u].z = c2 == (uint32_t)P.ncol ? cand_v : s_lut[ch][c2]; r2[u].w = c3 == (uint32_t)P.ncol ? cand_v : s_lut[ch][c3];
             }
@@ -547,8 +636,16 @@ __global__ __launch_bounds__(256, 3) void k_sparse_v(SparseParams P) {
             }
             float i2v[4] = {c_x.x, c_x.y, c_x.z, c_x.w};
             if (S0 && g >= 1) {
-                const uint32_t c0 = sparse_ci(c_pa.x, c_pa.y & never, crgb, (uint32_t)P.ncol), c1 = sparse_ci(c_pa.z, c_pa.w & never, crgb, (uint32_t)P.ncol);
-                const uint32_t c2 = sparse_ci(c_pb.x, c_pb.y & never, crgb, (uint32_t)P.ncol), c3 = sparse_ci(c_pb.z, c_pb.w & never, crgb, (uint32_t)P.ncol);
+                uint32_t c0, c1, c2, c3;
+                if (P.perceptual && !is_base) { // rows 4(g-1)..4(g-1)+3 of column x
+                    const uint32_t *bm = P.bitmap + (size_t)k * (G.W * G.H / 32);
+                    const int px0 = ((g - 1) << 2) * W + x;
+                    c0 = won_bit(bm, px0) ? (uint32_t)P.ncol : (c_pa.x >> 24); c1 = won_bit(bm, px0 + W) ? (uint32_t)P.ncol : (c_pa.z >> 24);
+                    c2 = won_bit(bm, px0 + 2 * W) ? (uint32_t)P.ncol : (c_pb.x >> 24); c3 = won_bit(bm, px0 + 3 * W) ? (uint32_t)P.ncol : (c_pb.z >> 24);
+                } else {
+                    c0 = sparse_ci(c_pa.x, c_pa.y & never, crgb, (uint32_t)P.ncol); c1 = sparse_ci(c_pa.z, c_pa.w & never, crgb, (uint32_t)P.ncol);
+                    c2 = sparse_ci(c_pb.x, c_pb.y & never, crgb, (uint32_t)P.ncol); c3 = sparse_ci(c_pb.z, c_pb.w & never, crgb, (uint32_t)P.ncol);
+                }
                 i2v[0] = c0 == (uint32_t)P.ncol ? cand_v : lut[c0]; i2v[1] = c1 == (uint32_t)P.ncol ? cand_v : lut[c1];
                 i2v[2] = c2 == (uint32_t)P.ncol ? cand_v : lut[c2]; i2v[3] = c3 == (uint32_t)P.ncol ? cand_v : lut[c3];
             }
