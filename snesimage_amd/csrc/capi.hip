@@ -112,10 +112,11 @@ struct snesimage_ctx {
     // per-chunk workspace
     float *d_work = nullptr, *d_cand_tab = nullptr, *d_cand_lab = nullptr;
     double *d_part = nullptr;
-    uint8_t *d_maps = nullptr, *d_mapsT = nullptr; // dither path: per-candidate maps
+    uint8_t *d_maps = nullptr, *d_mapsT = nullptr, *d_mapsC4 = nullptr, *d_mapsR4 = nullptr; // dither path: per-candidate maps
+    uint8_t *d_subC4 = nullptr, *d_subR4 = nullptr;
     // Additional launch lanes: chunk i of a candidate list runs on lane i % nlanes (lane 0 = the context's stream and the
     // workspace above), so the HBM-bound H pass of one chunk overlaps the VALU-bound V pass of another.
-    struct Lane { hipStream_t stream = nullptr; float *d_work = nullptr, *d_cand_tab = nullptr, *d_cand_lab = nullptr; double *d_part = nullptr; uint8_t *d_maps = nullptr, *d_mapsT = nullptr; hipEvent_t done = nullptr; };
+    struct Lane { hipStream_t stream = nullptr; float *d_work = nullptr, *d_cand_tab = nullptr, *d_cand_lab = nullptr; double *d_part = nullptr; uint8_t *d_maps = nullptr, *d_mapsT = nullptr, *d_mapsC4 = nullptr, *d_mapsR4 = nullptr; hipEvent_t done = nullptr; };
     std::vector<Lane> extra; uint32_t nlanes = 2; hipEvent_t ev_ready = nullptr;
     // Row-sparse scoring (kernels_sparse.hpp): one storage array for every lane's candidates plus the base image B
     struct Sparse {
@@ -152,8 +153,8 @@ struct snesimage_ctx {
 
 namespace {
 
-int32_t alloc_lane(snesimage_ctx *c, uint32_t chunk, float *&d_work, float *&d_cand_tab, float *&d_cand_lab, double *&d_part, uint8_t *&d_maps, uint8_t *&d_mapsT) {
-    dfree(d_work); dfree(d_cand_tab); dfree(d_cand_lab); dfree(d_part); dfree(d_maps); dfree(d_mapsT);
+int32_t alloc_lane(snesimage_ctx *c, uint32_t chunk, float *&d_work, float *&d_cand_tab, float *&d_cand_lab, double *&d_part, uint8_t *&d_maps, uint8_t *&d_mapsT, uint8_t *&d_mapsC4, uint8_t *&d_mapsR4) {
+    dfree(d_work); dfree(d_cand_tab); dfree(d_cand_lab); dfree(d_part); dfree(d_maps); dfree(d_mapsT); dfree(d_mapsC4); dfree(d_mapsR4);
     HIPCHK(hipMalloc(&d_work, sizeof(float) * (size_t)c->G.cand_stride * chunk));
     HIPCHK(hipMalloc(&d_cand_tab, sizeof(float) * 8 * (size_t)chunk));
     HIPCHK(hipMalloc(&d_cand_lab, sizeof(float) * 3 * (size_t)chunk));
@@ -161,6 +162,8 @@ int32_t alloc_lane(snesimage_ctx *c, uint32_t chunk, float *&d_work, float *&d_c
     if (c->dither) {
         HIPCHK(hipMalloc(&d_maps, c->npx * (size_t)chunk));
         HIPCHK(hipMalloc(&d_mapsT, c->npx * (size_t)chunk));
+        HIPCHK(hipMalloc(&d_mapsC4, c->npx * (size_t)chunk));
+        HIPCHK(hipMalloc(&d_mapsR4, c->npx * (size_t)chunk));
     }
     return SNES_OK;
 }
@@ -168,7 +171,7 @@ int32_t alloc_workspace(snesimage_ctx *c, uint32_t chunk) {
     if (c->chunk_alloc >= chunk && c->extra.size() + 1 >= c->nlanes) return SNES_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
     for (auto &L : c->extra) HIPCHK(hipStreamSynchronize(L.stream));
-    CHECK(alloc_lane(c, chunk, c->d_work, c->d_cand_tab, c->d_cand_lab, c->d_part, c->d_maps, c->d_mapsT));
+    CHECK(alloc_lane(c, chunk, c->d_work, c->d_cand_tab, c->d_cand_lab, c->d_part, c->d_maps, c->d_mapsT, c->d_mapsC4, c->d_mapsR4));
     if (!c->ev_ready) HIPCHK(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
     while (c->extra.size() + 1 < c->nlanes) {
         snesimage_ctx::Lane L;
@@ -176,7 +179,7 @@ int32_t alloc_workspace(snesimage_ctx *c, uint32_t chunk) {
         HIPCHK(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
         c->extra.push_back(L);
     }
-    for (auto &L : c->extra) CHECK(alloc_lane(c, chunk, L.d_work, L.d_cand_tab, L.d_cand_lab, L.d_part, L.d_maps, L.d_mapsT));
+    for (auto &L : c->extra) CHECK(alloc_lane(c, chunk, L.d_work, L.d_cand_tab, L.d_cand_lab, L.d_part, L.d_maps, L.d_mapsT, L.d_mapsC4, L.d_mapsR4));
     c->chunk_alloc = chunk;
     return SNES_OK;
 }
@@ -244,7 +247,7 @@ int32_t run_prep(snesimage_ctx *c, int mode, int sp, int si) {
     CHECK(ensure_tables(c));
     if (c->perceptual) CHECK(ensure_source(c));
     PrepParams P{};
-    P.orig = c->d_orig; P.tile_pal = c->d_tile_pal; P.pal_rgb8 = c->d_pal_rgb8; P.map = c->d_map; P.pack = c->d_pack; P.packT = c->d_packT; P.packC4 = c->d_packC4; P.packR4 = c->d_packR4;
+    P.orig = c->d_orig; P.tile_pal = c->d_tile_pal; P.pal_rgb8 = c->d_pal_rgb8; P.map = c->d_map; P.pack = c->d_pack; P.packT = c->d_packT; P.packC4 = c->d_packC4; P.packR4 = c->d_packR4; P.subC4 = c->d_subC4; P.subR4 = c->d_subR4;
     P.labpx = c->d_labpx; P.pal_lab = c->d_pal_lab;
     P.W = (int)c->W; P.H = (int)c->H; P.sub_size = (int)c->sub_size; P.ncol = c->ncol; P.mode = mode; P.sp = sp; P.si = si; P.perceptual = c->perceptual ? 1 : 0;
     hipLaunchKernelGGL(k_prep, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, P);
@@ -258,6 +261,13 @@ int32_t run_prep(snesimage_ctx *c, int mode, int sp, int si) {
 // (mode 2).  With dither every candidate gets its own map from k_dither; the pack is then only consulted for
 // the transparent-pixel marker, which any mode provides (mode 1 is the cheapest).
 int32_t prep_for_slot(snesimage_ctx *c, int sp, int si) { return c->dither ? run_prep(c, 1, -1, -1) : run_prep(c, 2, sp, si); }
+
+// k_dither instantiations: the 15-colour subpalettes of the SNES 4bpp modes get a fully unrolled entry search
+void launch_dither(snesimage_ctx *c, const DitherParams &Dp, uint32_t nblocks) {
+    if (c->perceptual) hipLaunchKernelGGL((k_dither<true, 0>), dim3(nblocks), dim3(128), 0, c->stream, Dp);
+    else if (c->sub_size == 15) hipLaunchKernelGGL((k_dither<false, 15>), dim3(nblocks), dim3(128), 0, c->stream, Dp);
+    else hipLaunchKernelGGL((k_dither<false, 0>), dim3(nblocks), dim3(128), 0, c->stream, Dp);
+}
 
 // Score nc candidates (device rgb5 list) given a prepared pack; errors -> d_errors[err_offset + k*err_stride].
 // slot_ci: colour index of the slot being replaced (dither path), or -1.
@@ -274,9 +284,12 @@ int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double
     if (use_maps) {
         DitherParams Dp{};
         Dp.orig = c->d_orig; Dp.tile_pal = c->d_tile_pal; Dp.pal_rgb8 = c->d_pal_rgb8; Dp.pal_lab = c->d_pal_lab; Dp.cand_tab = c->d_cand_tab; Dp.cand_lab = c->d_cand_lab;
-        Dp.lab_eotf = c->d_lab_eotf; Dp.maps = c->d_maps; Dp.mapsT = c->d_mapsT;
+        Dp.lab_eotf = c->d_lab_eotf; Dp.maps = c->d_maps; Dp.mapsC4 = c->d_mapsC4;
         Dp.W = (int)c->W; Dp.H = (int)c->H; Dp.sub_size = (int)c->sub_size; Dp.ncol = c->ncol; Dp.slot_ci = slot_ci; Dp.perceptual = c->perceptual ? 1 : 0;
-        hipLaunchKernelGGL(k_dither, dim3(nc), dim3(128), 0, c->stream, Dp);
+        launch_dither(c, Dp, nc);
+        // the transposed copy only feeds the generic scale-0 H pass
+        hipLaunchKernelGGL(k_maps_relayout, dim3((unsigned)((c->npx / 4 + 255) / 256), nc), dim3(256), 0, c->stream, c->d_maps, (int)c->W, (int)c->H,
+                           reinterpret_cast<uint32_t *>(c->d_mapsR4), (c->fast_mask & 1) ? (uint32_t *)nullptr : reinterpret_cast<uint32_t *>(c->d_mapsT));
         if (d_maps_out) HIPCHK(hipMemcpyAsync(d_maps_out, c->d_maps, c->npx * (size_t)nc, hipMemcpyDeviceToDevice, c->stream));
     } else if (d_maps_out) {
         MapsParams M{}; M.pack = c->d_pack; M.cand_tab = c->d_cand_tab; M.cand_lab = c->d_cand_lab; M.labpx = c->d_labpx; M.maps = d_maps_out;
@@ -288,11 +301,13 @@ int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double
         D.work = c->d_work; D.ncol = c->ncol; D.perceptual = c->perceptual ? 1 : 0; D.use_maps = use_maps ? 1 : 0; D.fast_mask = c->fast_mask & ~1; D.maps = c->d_maps; D.tile_pal = c->d_tile_pal; D.sub_size = (int)c->sub_size;
         hipLaunchKernelGGL(k_downscale_chain<true>, dim3((G.W / 32) * ((G.H + 31) / 32), nc), dim3(256), 0, c->stream, D);
     }
-    const bool fast0 = (c->fast_mask & 1) && !c->perceptual && !use_maps; // scale 0 takes its pixels from the pack (RGB keys)
+    const bool fast0 = (c->fast_mask & 1) && (use_maps || !c->perceptual); // scale 0 takes its pixels from the pack (RGB keys) or from the per-candidate maps (dither)
     auto is_fast = [&](int s) { return s == 0 ? fast0 : ((c->fast_mask >> s) & 1) != 0; };
     auto fast_params = [&](int s) {
         FastParams F{}; F.G = G; F.K = c->K; F.s = s; F.npairs = npairs; F.ncol = c->ncol;
         F.packC4 = c->d_packC4; F.packR4 = c->d_packR4; F.pal_xyb = c->d_pal_xyb; F.cand_tab = c->d_cand_tab;
+        F.use_maps = use_maps ? 1 : 0; F.mapsC4 = reinterpret_cast<const uint32_t *>(c->d_mapsC4); F.mapsR4 = reinterpret_cast<const uint32_t *>(c->d_mapsR4);
+        F.subC4 = reinterpret_cast<const uint32_t *>(c->d_subC4); F.subR4 = reinterpret_cast<const uint32_t *>(c->d_subR4);
         F.img1C4 = c->d_img1C4 + G.src_off[s]; F.img1R4 = c->d_img1R4 + G.src_off[s]; F.mu1R4 = c->d_mu1R4 + G.src_off[s]; F.s11R4 = c->d_s11R4 + G.src_off[s];
         F.work = c->d_work; F.part = c->d_part;
         return F;
@@ -463,7 +478,7 @@ struct LaneScope {
     LaneScope(snesimage_ctx *c_, snesimage_ctx::Lane *L_) : c(c_), L(L_) { swap(); }
     ~LaneScope() { swap(); }
     void swap() { std::swap(c->stream, L->stream); std::swap(c->d_work, L->d_work); std::swap(c->d_cand_tab, L->d_cand_tab); std::swap(c->d_cand_lab, L->d_cand_lab);
-                  std::swap(c->d_part, L->d_part); std::swap(c->d_maps, L->d_maps); std::swap(c->d_mapsT, L->d_mapsT); }
+                  std::swap(c->d_part, L->d_part); std::swap(c->d_maps, L->d_maps); std::swap(c->d_mapsT, L->d_mapsT); std::swap(c->d_mapsC4, L->d_mapsC4); std::swap(c->d_mapsR4, L->d_mapsR4); }
 };
 
 // errors of candidate j of the list go to d_errors[err_offset + j * err_stride]
@@ -510,9 +525,9 @@ int32_t do_optimize(snesimage_ctx *c) {
         hipLaunchKernelGGL(k_candidate_slot, dim3(1), dim3(64), 0, c->stream, c->d_cand_tab, 1, 0xffffffffu);
         DitherParams Dp{};
         Dp.orig = c->d_orig; Dp.tile_pal = c->d_tile_pal; Dp.pal_rgb8 = c->d_pal_rgb8; Dp.pal_lab = c->d_pal_lab; Dp.cand_tab = c->d_cand_tab; Dp.cand_lab = c->d_cand_lab;
-        Dp.lab_eotf = c->d_lab_eotf; Dp.maps = c->d_map; Dp.mapsT = c->d_mapsT;
+        Dp.lab_eotf = c->d_lab_eotf; Dp.maps = c->d_map;
         Dp.W = (int)c->W; Dp.H = (int)c->H; Dp.sub_size = (int)c->sub_size; Dp.ncol = c->ncol; Dp.slot_ci = 0xffffffffu; Dp.perceptual = c->perceptual ? 1 : 0;
-        hipLaunchKernelGGL(k_dither, dim3(1), dim3(128), 0, c->stream, Dp);
+        launch_dither(c, Dp, 1);
         HIPCHK(hipGetLastError());
         c->pack_valid = false;
     }
@@ -646,6 +661,7 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
         HIPCHK(hipMalloc(&c->d_packT, c->npx * 8));
         HIPCHK(hipMalloc(&c->d_packC4, c->npx * 8));
         HIPCHK(hipMalloc(&c->d_packR4, c->npx * 8));
+        if (c->dither) { HIPCHK(hipMalloc(&c->d_subC4, c->npx)); HIPCHK(hipMalloc(&c->d_subR4, c->npx)); }
         HIPCHK(hipMalloc(&c->d_eotf, 256 * 4));
         HIPCHK(hipMalloc(&c->d_lab_eotf, 256 * 4));
         HIPCHK(hipMalloc(&c->d_pal_rgb8, 256 * 4));
@@ -691,12 +707,12 @@ void snesimage_destroy(snesimage_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)drain_timing(c);
-    dfree(c->d_packC4); dfree(c->d_packR4); dfree(c->d_img1C4); dfree(c->d_img1R4); dfree(c->d_mu1R4); dfree(c->d_s11R4);
+    dfree(c->d_packC4); dfree(c->d_packR4); dfree(c->d_subC4); dfree(c->d_subR4); dfree(c->d_mapsC4); dfree(c->d_mapsR4); dfree(c->d_img1C4); dfree(c->d_img1R4); dfree(c->d_mu1R4); dfree(c->d_s11R4);
     dfree(c->d_orig); dfree(c->d_tile_pal); dfree(c->d_colors); dfree(c->d_map); dfree(c->d_pack); dfree(c->d_packT); dfree(c->d_eotf); dfree(c->d_lab_eotf);
     dfree(c->d_pal_rgb8); dfree(c->d_pal_lin); dfree(c->d_pal_xyb); dfree(c->d_pal_lab); dfree(c->d_lin0); dfree(c->d_img1); dfree(c->d_img1T); dfree(c->d_mu1); dfree(c->d_s11);
     dfree(c->d_labpx); dfree(c->d_labpxT); dfree(c->d_work); dfree(c->d_cand_tab); dfree(c->d_cand_lab); dfree(c->d_part); dfree(c->d_maps); dfree(c->d_mapsT);
     dfree(c->d_cand); dfree(c->d_cand_sel); dfree(c->d_errs); dfree(c->d_errs_sel); dfree(c->d_inc_err); dfree(c->d_last); dfree(c->d_scratch_err); dfree(c->d_dummy_cand);
-    for (auto &L : c->extra) { if (L.stream) (void)hipStreamSynchronize(L.stream); dfree(L.d_work); dfree(L.d_cand_tab); dfree(L.d_cand_lab); dfree(L.d_part); dfree(L.d_maps); dfree(L.d_mapsT); if (L.done) (void)hipEventDestroy(L.done); if (L.stream) (void)hipStreamDestroy(L.stream); }
+    for (auto &L : c->extra) { if (L.stream) (void)hipStreamSynchronize(L.stream); dfree(L.d_mapsC4); dfree(L.d_mapsR4); dfree(L.d_work); dfree(L.d_cand_tab); dfree(L.d_cand_lab); dfree(L.d_part); dfree(L.d_maps); dfree(L.d_mapsT); if (L.done) (void)hipEventDestroy(L.done); if (L.stream) (void)hipStreamDestroy(L.stream); }
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
     { auto &q = c->sp; if (q.base_stream) { (void)hipStreamSynchronize(q.base_stream); (void)hipStreamDestroy(q.base_stream); (void)hipEventDestroy(q.ev_base_in); (void)hipEventDestroy(q.ev_base_done); } dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.plist_count); dfree(q.cand_lab); dfree(q.bitmap); }
     kmeans_free(c->km);

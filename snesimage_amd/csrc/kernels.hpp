@@ -105,6 +105,7 @@ __global__ void k_candidate_tables(const uint8_t *__restrict__ rgb5, int n, cons
 struct PrepParams {
     const uint8_t *orig; const uint8_t *tile_pal; const uint32_t *pal_rgb8; uint8_t *map;
     unsigned long long *pack, *packT, *packC4, *packR4;
+    uint8_t *subC4, *subR4; // per pixel: subpalette base (sub * sub_size) of its tile, 255 if transparent (dither path)
     const float *labpx; const float *pal_lab; // perceptual only
     int W, H, sub_size, ncol, mode, sp, si, perceptual;
 };
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256) void k_prep(PrepParams P) {
     P.packT[(size_t)x * P.H + y] = w;
     P.packC4[idx_c4(x, y, P.H)] = w;
     P.packR4[idx_r4(x, y, P.W)] = w;
+    if (P.subC4) { const uint8_t sbv = opaque ? (uint8_t)base : (uint8_t)255; P.subC4[idx_c4(x, y, P.H)] = sbv; P.subR4[idx_r4(x, y, P.W)] = sbv; }
 }
 
 // Which colour index does pixel `pk` take for a candidate with 8-bit colour crgb / Lab clab?

@@ -24,6 +24,9 @@ struct FastParams {
     Geom G; BlurK K;
     int s, npairs, ncol;
     const unsigned long long *packC4, *packR4; // scale 0
+    // --dither: every candidate has its own palette_map (k_dither); the colour index of a pixel is then
+    // sub[px] + map[px] (sub = subpalette base of the pixel's tile, 255 = transparent), and the slot's index means the candidate
+    int use_maps; const uint32_t *mapsC4, *mapsR4, *subC4, *subR4; // 4 pixels per word, blocked like the pack
     const float *pal_xyb, *cand_tab;
     const float *img1C4;                       // source, this scale: [3][C4]
     const float *img1R4, *mu1R4, *s11R4;       // source, this scale: [3][R4]
@@ -36,6 +39,16 @@ __device__ __forceinline__ void resolve4(const uint4 a, const uint4 b, uint32_t 
     const uint32_t lo[4] = {a.x, a.z, b.x, b.z}, hi[4] = {a.y, a.w, b.y, b.w};
 #pragma unroll
     for (int j = 0; j < 4; j++) ci[j] = red_mean_key(crgb, lo[j] & 0x00ffffffu) < hi[j] ? ncol : (lo[j] >> 24);
+}
+
+// colour index of 4 pixels from their map bytes (dither path)
+__device__ __forceinline__ void resolve4_maps(uint32_t mw, uint32_t sw, uint32_t slot_ci, uint32_t ncol, uint32_t ci[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t sb = (sw >> (8 * j)) & 0xffu, m = (mw >> (8 * j)) & 0xffu;
+        const uint32_t c = sb == 255u ? ncol + 1u : sb + m;
+        ci[j] = c == slot_ci ? ncol : c;
+    }
 }
 
 // One step of the three recurrences of a plane.  A holds y[n-1], B holds y[n-2]; the new value is written
@@ -84,7 +97,10 @@ __global__ __launch_bounds__(64) void k_hpass_fast(FastParams P) {
     }
     const float4 *in1 = reinterpret_cast<const float4 *>(P.img1C4 + (size_t)ch * ns) + y;                                   // advances by H per group
     const float4 *in2 = S0 ? nullptr : reinterpret_cast<const float4 *>(P.work + (size_t)cand * G.cand_stride + G.off_xybT[s] + (size_t)ch * ns) + y;
-    const uint4 *pk = S0 ? reinterpret_cast<const uint4 *>(P.packC4) + 2 * (size_t)y : nullptr;                              // advances by 2H per group
+    const bool use_maps = S0 && P.use_maps;
+    const uint32_t slot_ci = S0 ? __float_as_uint(P.cand_tab[8 * (size_t)cand + 7]) : 0u;
+    const uint4 *pk = (S0 && !use_maps) ? reinterpret_cast<const uint4 *>(P.packC4) + 2 * (size_t)y : nullptr;                 // advances by 2H per group
+    const uint32_t *mp = use_maps ? P.mapsC4 + (size_t)cand * (ns >> 2) + y : nullptr, *sbp = use_maps ? P.subC4 + y : nullptr; // advance by H per group
     float *hout = P.work + (size_t)cand * G.cand_stride + G.off_hout[s] + (size_t)(ch * 3) * ns;
     // XT4 offset of (x = 4(g-1) + (lane&3), y = 64*yb + (lane&~3)); per group x advances by 4 -> +16 floats, and by a whole
     // column block (H*64 floats) every 16 groups
@@ -105,8 +121,9 @@ __global__ __launch_bounds__(64) void k_hpass_fast(FastParams P) {
     const int G4 = W >> 2;
     uint4 n_pa = make_uint4(0, 0, 0, 0), n_pb = n_pa;
     r1[0] = in1[0];
-    if (S0) { n_pa = pk[0]; n_pb = pk[1]; } else r2[0] = in2[0];
-    in1 += H; if (S0) pk += 2 * (size_t)H; else in2 += H;
+    if (use_maps) { n_pa.x = mp[0]; n_pa.y = sbp[0]; mp += H; sbp += H; }
+    else if (S0) { n_pa = pk[0]; n_pb = pk[1]; pk += 2 * (size_t)H; } else { r2[0] = in2[0]; in2 += H; }
+    in1 += H;
 
     for (int g0 = 0; g0 <= G4; g0 += 5) {
 #pragma unroll
@@ -117,11 +134,12 @@ __global__ __launch_bounds__(64) void k_hpass_fast(FastParams P) {
             const uint4 c_pa = n_pa, c_pb = n_pb;
             if (g + 1 < G4) { // prefetch group g+1 straight into its ring slot
                 r1[un] = in1[0]; in1 += H;
-                if (S0) { n_pa = pk[0]; n_pb = pk[1]; pk += 2 * (size_t)H; } else { r2[un] = in2[0]; in2 += H; }
+                if (use_maps) { n_pa.x = mp[0]; n_pa.y = sbp[0]; mp += H; sbp += H; }
+                else if (S0) { n_pa = pk[0]; n_pb = pk[1]; pk += 2 * (size_t)H; } else { r2[un] = in2[0]; in2 += H; }
             } else { r1[un] = make_float4(0.f, 0.f, 0.f, 0.f); r2[un] = r1[un]; n_pa = make_uint4(0, 0, 0, 0); n_pb = n_pa; }
             if (S0 && g < G4) {
                 uint32_t ci[4];
-                resolve4(c_pa, c_pb, crgb, (uint32_t)P.ncol, ci);
+                if (use_maps) resolve4_maps(c_pa.x, c_pa.y, slot_ci, (uint32_t)P.ncol, ci); else resolve4(c_pa, c_pb, crgb, (uint32_t)P.ncol, ci);
                 r2[u].x = (ci[0] == (uint32_t)P.ncol) ? cand_v : s_lut[ci[0]];
                 r2[u].y = (ci[1] == (uint32_t)P.ncol) ? cand_v : s_lut[ci[1]];
                 r2[u].z = (ci[2] == (uint32_t)P.ncol) ? cand_v : s_lut[ci[2]];
@@ -192,7 +210,10 @@ __global__ __launch_bounds__(256) void k_vpass_fast(FastParams P) {
     const float4 *mu1 = reinterpret_cast<const float4 *>(P.mu1R4 + (size_t)ch * ns) + x;
     const float4 *s11 = reinterpret_cast<const float4 *>(P.s11R4 + (size_t)ch * ns) + x;
     const float4 *xyb = S0 ? nullptr : reinterpret_cast<const float4 *>(P.work + (size_t)cand * G.cand_stride + G.off_xyb[s] + (size_t)ch * ns) + x;
-    const uint4 *pk = S0 ? reinterpret_cast<const uint4 *>(P.packR4) + 2 * (size_t)x : nullptr;
+    const bool use_maps = S0 && P.use_maps;
+    const uint32_t slot_ci = S0 ? __float_as_uint(P.cand_tab[8 * (size_t)cand + 7]) : 0u;
+    const uint4 *pk = (S0 && !use_maps) ? reinterpret_cast<const uint4 *>(P.packR4) + 2 * (size_t)x : nullptr;
+    const uint32_t *mp = use_maps ? P.mapsR4 + (size_t)cand * (ns >> 2) + x : nullptr, *sbp = use_maps ? P.subR4 + x : nullptr; // advance by W per row group
 
     const float n2_0 = P.K.n2[0], n2_1 = P.K.n2[1], n2_2 = P.K.n2[2];
     const float d1_0 = P.K.d1[0], d1_1 = P.K.d1[1], d1_2 = P.K.d1[2];
@@ -225,12 +246,13 @@ __global__ __launch_bounds__(256) void k_vpass_fast(FastParams P) {
             else { ring[0][un] = make_float4(0.f, 0.f, 0.f, 0.f); ring[1][un] = ring[0][un]; ring[2][un] = ring[0][un]; }
             if (g < H4) { // inputs of the maps of rows 4g..4g+3, consumed in the next iteration
                 n_i1 = img1[0]; n_m1 = mu1[0]; n_s11 = s11[0]; img1 += W; mu1 += W; s11 += W;
-                if (S0) { n_pa = pk[0]; n_pb = pk[1]; pk += 2 * (size_t)W; } else { n_x = xyb[0]; xyb += W; }
+                if (use_maps) { n_pa.x = mp[0]; n_pa.y = sbp[0]; mp += W; sbp += W; }
+                else if (S0) { n_pa = pk[0]; n_pb = pk[1]; pk += 2 * (size_t)W; } else { n_x = xyb[0]; xyb += W; }
             }
             float i2v[4] = {c_x.x, c_x.y, c_x.z, c_x.w};
             if (S0 && g >= 1) {
                 uint32_t ci[4];
-                resolve4(c_pa, c_pb, crgb, (uint32_t)P.ncol, ci);
+                if (use_maps) resolve4_maps(c_pa.x, c_pa.y, slot_ci, (uint32_t)P.ncol, ci); else resolve4(c_pa, c_pb, crgb, (uint32_t)P.ncol, ci);
 #pragma unroll
                 for (int j = 0; j < 4; j++) i2v[j] = (ci[j] == (uint32_t)P.ncol) ? cand_v : lut[ci[j]];
             }

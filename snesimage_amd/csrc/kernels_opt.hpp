@@ -47,28 +47,59 @@ __global__ __launch_bounds__(256) void k_pixel_lab(const uint8_t *__restrict__ o
 // ------------------------------------------------------------------------------------------------
 struct DitherParams {
     const uint8_t *orig; const uint8_t *tile_pal; const uint32_t *pal_rgb8; const float *pal_lab; const float *cand_tab; const float *cand_lab; const float *lab_eotf;
-    uint8_t *maps, *mapsT;
+    uint8_t *maps, *mapsC4; // row-major and the column-blocked layout of kernels_fast.hpp (k_maps_relayout derives the others)
     int W, H, sub_size, ncol; uint32_t slot_ci; int perceptual;
 };
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+
+// RGB nearest entry among n (<= 8) consecutive table rows: 8*red_mean_key + u for row u, so the smallest value is the
+// first minimal key.  Per entry the table holds {r | b<<16, 8*(1024+r) | 8*(1534-r)<<16, g, rgb8}; with the target's
+// {r | b<<16, 8r | (-8r)<<16, g} one key is three packed 16-bit ops (differences, their squares <= 65,025, the two
+// red-mean weights <= 12,272), the green square and one v_dot2_u32_u16 — every intermediate exact.
+template <int N>
+__device__ __forceinline__ uint32_t dither_group_min(const uint4 *__restrict__ ent, uint32_t t1, uint32_t tw, int tg) {
+    uint32_t k[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        if (u < N) {
+            const uint4 e = ent[u];
+            const u16x2 d = as_u16x2(e.x) - as_u16x2(t1);
+            const u16x2 sq = d * d;
+            const u16x2 wg = as_u16x2(e.y) + as_u16x2(tw);
+            const int dg = (int)e.z - tg;
+            k[u] = __builtin_amdgcn_udot2(sq, wg, ((uint32_t)(dg * dg) << 14) | (uint32_t)u, false);
+        } else k[u] = 0xffffffffu;
+    }
+    return min(min(min(k[0], k[1]), min(k[2], k[3])), min(min(k[4], k[5]), min(k[6], k[7])));
+}
+
+// PERC: CIEDE2000 in Lab (the --perceptual-palettes remap); SUB: subpalette size known at compile time (0 = read it from P)
+template <bool PERC, int SUB>
 __global__ __launch_bounds__(128) void k_dither(DitherParams P) {
-    __shared__ uint32_t s_rgb8[256];
-    __shared__ float s_lab[256 * 3];
-    __shared__ float s_eotf[256];
+    __shared__ uint4 s_ent[256];
+    __shared__ float s_lab[PERC ? 256 * 3 : 1];
+    __shared__ float s_eotf[PERC ? 256 : 1];
     __shared__ double ring[128][4][3];
+    __shared__ uint8_t s_tile[1024];
     const int j = threadIdx.x;
     const int cand = blockIdx.x;
-    const int W = P.W, H = P.H;
+    constexpr int W = 256; // snesimage_create admits no other width; a constant keeps the per-step index arithmetic to shifts
+    const int H = P.H;
+    const int sub_size = SUB ? SUB : P.sub_size;
     for (int i = j; i < P.ncol; i += 128) {
-        s_rgb8[i] = P.pal_rgb8[i];
-        if (P.perceptual) { s_lab[3 * i] = P.pal_lab[3 * i]; s_lab[3 * i + 1] = P.pal_lab[3 * i + 1]; s_lab[3 * i + 2] = P.pal_lab[3 * i + 2]; }
+        uint32_t c = P.pal_rgb8[i];
+        if ((uint32_t)i == P.slot_ci) c = __float_as_uint(P.cand_tab[8 * (size_t)cand + 6]);
+        const uint32_t r = c & 0xff, g = (c >> 8) & 0xff, b = (c >> 16) & 0xff;
+        s_ent[i] = make_uint4(r | (b << 16), (8u * (1024u + r)) | ((8u * (1534u - r)) << 16), g, c);
+        if (PERC) {
+            const float *src = ((uint32_t)i == P.slot_ci) ? P.cand_lab + 3 * (size_t)cand : P.pal_lab + 3 * (size_t)i;
+            s_lab[3 * i] = src[0]; s_lab[3 * i + 1] = src[1]; s_lab[3 * i + 2] = src[2];
+        }
     }
-    if (P.perceptual) for (int i = j; i < 256; i += 128) s_eotf[i] = P.lab_eotf[i];
-    __syncthreads();
-    if (j == 0 && P.slot_ci < (uint32_t)P.ncol) {
-        s_rgb8[P.slot_ci] = __float_as_uint(P.cand_tab[8 * (size_t)cand + 6]);
-        if (P.perceptual) { s_lab[3 * P.slot_ci] = P.cand_lab[3 * cand]; s_lab[3 * P.slot_ci + 1] = P.cand_lab[3 * cand + 1]; s_lab[3 * P.slot_ci + 2] = P.cand_lab[3 * cand + 2]; }
-    }
+    if (PERC) for (int i = j; i < 256; i += 128) s_eotf[i] = P.lab_eotf[i];
+    for (int i = j; i < 1024; i += 128) s_tile[i] = P.tile_pal[i];
     for (int q = 0; q < 4; q++) { ring[j][q][0] = 0.0; ring[j][q][1] = 0.0; ring[j][q][2] = 0.0; }
     __syncthreads();
     const double w0 = 7.0 / 16.0, w1 = 3.0 / 16.0, w2 = 5.0 / 16.0, w3 = 1.0 / 16.0, mult = 0.8;
@@ -76,67 +107,118 @@ __global__ __launch_bounds__(128) void k_dither(DitherParams P) {
     const int total_steps = 2 * 127 + rows_per_thread * W;
     double left[3] = {0.0, 0.0, 0.0}; // v(x-1, y) of this thread's current row
     uint8_t *map = P.maps + (size_t)cand * W * H;
-    uint8_t *mapT = P.mapsT ? P.mapsT + (size_t)cand * W * H : nullptr;
+    uint32_t *map4 = reinterpret_cast<uint32_t *>(map);
+    uint32_t *mapC4 = P.mapsC4 ? reinterpret_cast<uint32_t *>(P.mapsC4 + (size_t)cand * W * H) : nullptr;
+    uint32_t macc = 0; // the four map bytes of the current x quad: one word store instead of scattered byte stores
     const int up = (j + 127) & 127; // thread owning row y-1
+    // the source pixels of the NEXT x quad are fetched while the current quad is processed (the step is a dependent chain)
+    const uint4 *orig4 = reinterpret_cast<const uint4 *>(P.orig);
+    uint4 o_cur = make_uint4(0, 0, 0, 0), o_nxt = (j < H) ? orig4[(size_t)j * (W >> 2)] : make_uint4(0, 0, 0, 0);
     for (int t = 0; t < total_steps; t++) {
         const int local = t - 2 * j; // position in this thread's 512-pixel stream
-        double v[3] = {0.0, 0.0, 0.0};
-        bool act = false; int x = 0, y = 0;
-        if (local >= 0 && local < rows_per_thread * W) {
-            x = local % W; y = j + 128 * (local / W);
-            act = y < H;
-        }
+        const int x = local & (W - 1), y = j + 128 * (local >> 8);
+        const bool act = local >= 0 && local < rows_per_thread * W && y < H;
         if (act) {
-            if (x == 0) { left[0] = 0.0; left[1] = 0.0; left[2] = 0.0; }
-            double e[3];
+            // every operand is fetched unconditionally and the border cases are selects, so the step has no divergent
+            // branches and its LDS reads are all in flight together
+            const double *ru0 = ring[up][(x - 1) & 3], *ru1 = ring[up][x & 3], *ru2 = ring[up][(x + 1) & 3];
+            const int base = (int)s_tile[(x >> 3) + (y >> 3) * (W >> 3)] * sub_size;
+            double r0[3], r1[3], r2[3];
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                double acc = 0.0;
-                if (y > 0) {
-                    if (x > 0) acc += ring[up][(x - 1) & 3][c] * mult * w3;
-                    acc += ring[up][x & 3][c] * mult * w2;
-                    if (x + 1 < W) acc += ring[up][(x + 1) & 3][c] * mult * w1;
-                }
-                if (x > 0) acc += left[c] * mult * w0;
-                e[c] = acc;
+            for (int c = 0; c < 3; c++) { r0[c] = ru0[c]; r1[c] = ru1[c]; r2[c] = ru2[c]; }
+            if ((x & 3) == 0) { // this thread's stream continues with (x+4, y), then row y+128
+                o_cur = o_nxt;
+                const int ln = local + 4;
+                const int xn = ln & (W - 1), yn = j + 128 * (ln >> 8);
+                if (ln < rows_per_thread * W && yn < H) o_nxt = orig4[((size_t)yn * W + xn) >> 2];
             }
-            const size_t px = (size_t)y * W + x;
-            const uint32_t o = reinterpret_cast<const uint32_t *>(P.orig)[px];
+            const uint32_t o = (x & 2) ? ((x & 1) ? o_cur.w : o_cur.z) : ((x & 1) ? o_cur.y : o_cur.x);
             const bool opaque = (o >> 24) != 0;
-            double target[3] = {(double)(o & 0xff) + e[0], (double)((o >> 8) & 0xff) + e[1], (double)((o >> 16) & 0xff) + e[2]};
+            const bool hasU = y > 0, hasL = x > 0, hasUL = hasU && hasL, hasUR = hasU && (x + 1 < W);
+            double e[3], target[3];
             uint32_t tq[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                double cl = target[c] < 0.0 ? 0.0 : (target[c] > 255.0 ? 255.0 : target[c]);
-                tq[c] = (uint32_t)round(cl); // Rust f64::round: half away from zero
+                double acc = 0.0;
+                const double a0 = acc + r0[c] * mult * w3; acc = hasUL ? a0 : acc;
+                const double a1 = acc + r1[c] * mult * w2; acc = hasU ? a1 : acc;
+                const double a2 = acc + r2[c] * mult * w1; acc = hasUR ? a2 : acc;
+                const double a3 = acc + left[c] * mult * w0; acc = hasL ? a3 : acc;
+                e[c] = acc;
+                target[c] = (double)((o >> (8 * c)) & 0xff) + acc;
+                const double cl = fmin(fmax(target[c], 0.0), 255.0);
+                const double tr = trunc(cl); // Rust f64::round: half away from zero (cl >= 0)
+                tq[c] = (uint32_t)(tr + ((cl - tr >= 0.5) ? 1.0 : 0.0));
             }
-            const uint32_t trgb = tq[0] | (tq[1] << 8) | (tq[2] << 16);
-            const int base = (int)P.tile_pal[(x >> 3) + (y >> 3) * (W >> 3)] * P.sub_size;
             int best = 0;
-            if (!P.perceptual) {
-                uint32_t bk = 0xffffffffu;
-                for (int i = 0; i < P.sub_size; i++) { uint32_t k = red_mean_key(s_rgb8[base + i], trgb); if (i == 0 || k < bk) { bk = k; best = i; } }
+            if (!PERC) {
+                const uint32_t t1 = tq[0] | (tq[2] << 16), tw = (8u * tq[0]) | ((0u - 8u * tq[0]) << 16);
+                const int tg = (int)tq[1];
+                uint32_t bk = 0xffffffffu; int bbase = 0;
+                if (SUB) {
+#pragma unroll
+                    for (int i0 = 0; i0 < SUB; i0 += 8) {
+                        const uint32_t g = (SUB - i0 >= 8) ? dither_group_min<8>(s_ent + base + i0, t1, tw, tg)
+                                                           : dither_group_min<(SUB & 7) ? (SUB & 7) : 8>(s_ent + base + i0, t1, tw, tg);
+                        if (i0 == 0 || (g >> 3) < (bk >> 3)) { bk = g; bbase = i0; }
+                    }
+                    best = bbase + (int)(bk & 7);
+                } else {
+                    int i0 = 0;
+                    for (; i0 + 8 <= sub_size; i0 += 8) {
+                        const uint32_t g = dither_group_min<8>(s_ent + base + i0, t1, tw, tg);
+                        if (i0 == 0 || (g >> 3) < (bk >> 3)) { bk = g; bbase = i0; }
+                    }
+                    best = bbase + (int)(bk & 7);
+                    uint32_t bkey = bk >> 3;
+                    for (; i0 < sub_size; i0++) { // ragged tail, one entry at a time
+                        const uint32_t g = dither_group_min<1>(s_ent + base + i0, t1, tw, tg) >> 3;
+                        if (i0 == 0 || g < bkey) { bkey = g; best = i0; }
+                    }
+                }
             } else {
                 Lab tl = linear_to_lab(s_eotf[tq[0]], s_eotf[tq[1]], s_eotf[tq[2]]);
                 float bd = 0.0f;
-                for (int i = 0; i < P.sub_size; i++) {
+                for (int i = 0; i < sub_size; i++) {
                     Lab el; el.l = s_lab[3 * (base + i)]; el.a = s_lab[3 * (base + i) + 1]; el.b = s_lab[3 * (base + i) + 2];
                     float d = ciede2000(el, tl);
                     if (i == 0 || d < bd) { bd = d; best = i; }
                 }
             }
             const uint8_t m = opaque ? (uint8_t)best : 0;
-            map[px] = m;
-            if (mapT) mapT[(size_t)x * H + y] = m;
-            const uint32_t nc = s_rgb8[base + best];
-            if (opaque) { v[0] = target[0] - (double)(nc & 0xff); v[1] = target[1] - (double)((nc >> 8) & 0xff); v[2] = target[2] - (double)((nc >> 16) & 0xff); }
-            else { v[0] = e[0]; v[1] = e[1]; v[2] = e[2]; } // transparent pixels forward their incoming error (lib.rs:469-474)
-            left[0] = v[0]; left[1] = v[1]; left[2] = v[2];
+            macc = (macc >> 8) | ((uint32_t)m << 24);
+            if ((x & 3) == 3) {
+                const size_t px = (size_t)y * W + x;
+                map4[px >> 2] = macc;
+                if (mapC4) mapC4[idx_c4(x & ~3, y, H) >> 2] = macc;
+            }
+            const uint32_t nc = s_ent[base + best].w;
+            double v[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const double d = target[c] - (double)((nc >> (8 * c)) & 0xff);
+                v[c] = opaque ? d : e[c]; // transparent pixels forward their incoming error (lib.rs:469-474)
+                left[c] = v[c];
+            }
+            // Row y-1 is two columns ahead (t = x + 2y): at this step it writes slot (x+2)&3 while this thread read slots
+            // (x-1), x, (x+1) & 3 — never the same slot, so one barrier per step orders everything.
+            ring[j][x & 3][0] = v[0]; ring[j][x & 3][1] = v[1]; ring[j][x & 3][2] = v[2];
         }
-        __syncthreads(); // every read of the ring for step t is done
-        if (act) { ring[j][x & 3][0] = v[0]; ring[j][x & 3][1] = v[1]; ring[j][x & 3][2] = v[2]; }
         __syncthreads();
     }
+}
+
+// Row-blocked (R4: [y/4][x][y%4]) and, on request, transposed ([x][y]) copies of the row-major per-candidate maps.
+// Both hold the same word — rows 4q..4q+3 of column x — at different places.
+__global__ __launch_bounds__(256) void k_maps_relayout(const uint8_t *__restrict__ maps, int W, int H, uint32_t *__restrict__ r4, uint32_t *__restrict__ mT) {
+    const int i = blockIdx.x * 256 + threadIdx.x; // (q, x)
+    if (i >= W * (H >> 2)) return;
+    const size_t cb = (size_t)blockIdx.y * W * H;
+    const int q = i / W, x = i - q * W;
+    const uint8_t *m = maps + cb + (size_t)(4 * q) * W + x;
+    const uint32_t w = (uint32_t)m[0] | ((uint32_t)m[W] << 8) | ((uint32_t)m[2 * W] << 16) | ((uint32_t)m[3 * W] << 24);
+    r4[(cb >> 2) + i] = w;
+    if (mT) mT[(cb >> 2) + (size_t)x * (H >> 2) + q] = w;
 }
 
 // ---- optimizer step: candidates and commit -------------------------------------------------------

@@ -70,7 +70,11 @@ def test_device_lab_and_ciede_bit_exact(S, O):
 
 # ---- remap (optimize) -----------------------------------------------------------------------------
 @pytest.mark.parametrize("count,size,flags", [(1, 15, {}), (8, 15, {}), (4, 7, {}), (8, 15, {"perceptual": True}),
-                                              (8, 15, {"dither": True}), (2, 3, {"dither": True, "perceptual": True})])
+                                              (8, 15, {"dither": True}), (2, 3, {"dither": True, "perceptual": True}),
+                                              # entry-search shapes of the dither kernel: ragged tail only, one full group of 8,
+                                              # group + tail, two groups, two groups + tail
+                                              (4, 3, {"dither": True}), (3, 8, {"dither": True}), (2, 12, {"dither": True}),
+                                              (10, 16, {"dither": True}), (2, 21, {"dither": True})])
 def test_optimize_map_bit_exact(S, O, img256, img256_alpha, count, size, flags):
     for img in (img256, img256_alpha):
         g, o = pair(S, O, img, count, size, **flags)
