@@ -114,9 +114,13 @@ struct snesimage_ctx {
     double *d_part = nullptr;
     uint8_t *d_maps = nullptr, *d_mapsT = nullptr, *d_mapsC4 = nullptr, *d_mapsR4 = nullptr; // dither path: per-candidate maps
     uint8_t *d_subC4 = nullptr, *d_subR4 = nullptr;
+    // dither path: every lane keeps the map of the best candidate it has scored in the current list, so that the commit
+    // takes the winner's map instead of dithering the image again (lib.rs:237 re-runs optimize() on the winner's palette)
+    uint8_t *d_bestmap = nullptr, *d_bestmaps_all = nullptr; BestRec *d_bestrec = nullptr, *d_bestrecs_all = nullptr; int *d_skip = nullptr;
+    bool best_valid = false, map_synced = false; // records belong to the list being committed; d_map is optimize() of the current palette
     // Additional launch lanes: chunk i of a candidate list runs on lane i % nlanes (lane 0 = the context's stream and the
     // workspace above), so the HBM-bound H pass of one chunk overlaps the VALU-bound V pass of another.
-    struct Lane { hipStream_t stream = nullptr; float *d_work = nullptr, *d_cand_tab = nullptr, *d_cand_lab = nullptr; double *d_part = nullptr; uint8_t *d_maps = nullptr, *d_mapsT = nullptr, *d_mapsC4 = nullptr, *d_mapsR4 = nullptr; hipEvent_t done = nullptr; };
+    struct Lane { hipStream_t stream = nullptr; float *d_work = nullptr, *d_cand_tab = nullptr, *d_cand_lab = nullptr; double *d_part = nullptr; uint8_t *d_maps = nullptr, *d_mapsT = nullptr, *d_mapsC4 = nullptr, *d_mapsR4 = nullptr, *d_bestmap = nullptr; BestRec *d_bestrec = nullptr; hipEvent_t done = nullptr; };
     std::vector<Lane> extra; uint32_t nlanes = 2; hipEvent_t ev_ready = nullptr;
     // Row-sparse scoring (kernels_sparse.hpp): one storage array for every lane's candidates plus the base image B
     struct Sparse {
@@ -180,6 +184,13 @@ int32_t alloc_workspace(snesimage_ctx *c, uint32_t chunk) {
         c->extra.push_back(L);
     }
     for (auto &L : c->extra) CHECK(alloc_lane(c, chunk, L.d_work, L.d_cand_tab, L.d_cand_lab, L.d_part, L.d_maps, L.d_mapsT, L.d_mapsC4, L.d_mapsR4));
+    if (c->dither && !c->d_bestmaps_all) {
+        HIPCHK(hipMalloc(&c->d_bestmaps_all, c->npx * (size_t)c->nlanes));
+        HIPCHK(hipMalloc(&c->d_bestrecs_all, sizeof(BestRec) * c->nlanes));
+        HIPCHK(hipMalloc(&c->d_skip, sizeof(int)));
+        c->d_bestmap = c->d_bestmaps_all; c->d_bestrec = c->d_bestrecs_all;
+        for (size_t l = 0; l < c->extra.size(); l++) { c->extra[l].d_bestmap = c->d_bestmaps_all + (l + 1) * c->npx; c->extra[l].d_bestrec = c->d_bestrecs_all + (l + 1); }
+    }
     c->chunk_alloc = chunk;
     return SNES_OK;
 }
@@ -352,6 +363,7 @@ int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double
         if (s == 0 && c->timing) HIPCHK(hipEventRecord(tr.ev[4], c->stream));
     }
     hipLaunchKernelGGL(k_final_score, dim3((nc + 63) / 64), dim3(64), 0, c->stream, c->d_part, (int)nc, G, d_errors, err_stride, err_offset);
+    if (use_maps) hipLaunchKernelGGL(k_keep_best, dim3(1), dim3(1024), 0, c->stream, d_errors, err_stride, err_offset, (int)nc, c->d_maps, (int)c->npx, c->d_bestrec, c->d_bestmap);
     HIPCHK(hipGetLastError());
     if (c->timing) { HIPCHK(hipEventRecord(tr.ev[5], c->stream)); c->t_pending.push_back(tr); }
     return SNES_OK;
@@ -478,7 +490,8 @@ struct LaneScope {
     LaneScope(snesimage_ctx *c_, snesimage_ctx::Lane *L_) : c(c_), L(L_) { swap(); }
     ~LaneScope() { swap(); }
     void swap() { std::swap(c->stream, L->stream); std::swap(c->d_work, L->d_work); std::swap(c->d_cand_tab, L->d_cand_tab); std::swap(c->d_cand_lab, L->d_cand_lab);
-                  std::swap(c->d_part, L->d_part); std::swap(c->d_maps, L->d_maps); std::swap(c->d_mapsT, L->d_mapsT); std::swap(c->d_mapsC4, L->d_mapsC4); std::swap(c->d_mapsR4, L->d_mapsR4); }
+                  std::swap(c->d_part, L->d_part); std::swap(c->d_maps, L->d_maps); std::swap(c->d_mapsT, L->d_mapsT); std::swap(c->d_mapsC4, L->d_mapsC4); std::swap(c->d_mapsR4, L->d_mapsR4);
+                  std::swap(c->d_bestmap, L->d_bestmap); std::swap(c->d_bestrec, L->d_bestrec); }
 };
 
 // errors of candidate j of the list go to d_errors[err_offset + j * err_stride]
@@ -490,6 +503,7 @@ int32_t score_list(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t n, double *
     const uint32_t nl = nchunks < c->nlanes ? nchunks : c->nlanes;
     const bool sparse = c->sp.enabled && !d_maps_out && sp >= 0 && n >= c->sp.min_n && c->pack_mode == 2;
     if (sparse) { CHECK(sparse_alloc(c)); CHECK(sparse_base_pass(c)); }
+    if (c->dither) { hipLaunchKernelGGL(k_reset_best, dim3(1), dim3(64), 0, c->stream, c->d_bestrecs_all, (int)c->nlanes); c->best_valid = true; }
     if (nl > 1) {
         HIPCHK(hipEventRecord(c->ev_ready, c->stream)); // pack, tables, candidates are ready
         for (uint32_t l = 1; l < nl; l++) HIPCHK(hipStreamWaitEvent(c->extra[l - 1].stream, c->ev_ready, 0));
@@ -512,7 +526,7 @@ int32_t score_list(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t n, double *
 }
 
 // optimize() on the current palette: no-dither -> argmin per pixel; dither -> serial error diffusion kernel
-int32_t do_optimize(snesimage_ctx *c) {
+int32_t do_optimize(snesimage_ctx *c, bool may_skip = false) {
     CHECK(ensure_tables(c));
     if (!c->dither) {
         c->pack_valid = false;
@@ -525,13 +539,13 @@ int32_t do_optimize(snesimage_ctx *c) {
         hipLaunchKernelGGL(k_candidate_slot, dim3(1), dim3(64), 0, c->stream, c->d_cand_tab, 1, 0xffffffffu);
         DitherParams Dp{};
         Dp.orig = c->d_orig; Dp.tile_pal = c->d_tile_pal; Dp.pal_rgb8 = c->d_pal_rgb8; Dp.pal_lab = c->d_pal_lab; Dp.cand_tab = c->d_cand_tab; Dp.cand_lab = c->d_cand_lab;
-        Dp.lab_eotf = c->d_lab_eotf; Dp.maps = c->d_map;
+        Dp.lab_eotf = c->d_lab_eotf; Dp.maps = c->d_map; Dp.skip = may_skip ? c->d_skip : nullptr;
         Dp.W = (int)c->W; Dp.H = (int)c->H; Dp.sub_size = (int)c->sub_size; Dp.ncol = c->ncol; Dp.slot_ci = 0xffffffffu; Dp.perceptual = c->perceptual ? 1 : 0;
         launch_dither(c, Dp, 1);
         HIPCHK(hipGetLastError());
         c->pack_valid = false;
     }
-    c->inc_valid = false;
+    c->inc_valid = false; c->map_synced = true;
     return SNES_OK;
 }
 
@@ -594,8 +608,18 @@ int32_t commit(snesimage_ctx *c, const double *d_errors, uint32_t n, uint32_t me
     HIPCHK(hipGetLastError());
     c->tables_valid = false;
     c->pack_valid = false;
-    CHECK(do_optimize(c)); // lib.rs:237 / 281 / 325 (and :906)
-    c->inc_valid = true;   // k_commit left the committed state's error in d_inc_err (lib.rs:910 recomputes the same value)
+    bool may_skip = false;
+    if (c->dither && c->d_skip) { // the winner's map is optimize() of the committed palette when a lane of this device scored it
+        hipLaunchKernelGGL(k_take_best_map, dim3(1), dim3(1024), 0, c->stream, c->d_last, c->d_bestrecs_all, c->best_valid ? (int)c->nlanes : 0, c->d_bestmaps_all, (int)c->npx,
+                           c->map_synced ? 1 : 0, c->d_map, c->d_skip);
+        may_skip = true;
+    }
+    c->best_valid = false;
+    const bool was_synced = c->map_synced;
+    CHECK(do_optimize(c, may_skip)); // lib.rs:237 / 281 / 325 (and :906)
+    // k_commit left the committed state's error in d_inc_err (lib.rs:910 recomputes the same value) — unless the step started
+    // from a map that did not belong to its palette and kept the palette: then optimize() has just replaced that map
+    c->inc_valid = was_synced;
     return SNES_OK;
 }
 
@@ -710,6 +734,7 @@ void snesimage_destroy(snesimage_ctx *c) {
     dfree(c->d_packC4); dfree(c->d_packR4); dfree(c->d_subC4); dfree(c->d_subR4); dfree(c->d_mapsC4); dfree(c->d_mapsR4); dfree(c->d_img1C4); dfree(c->d_img1R4); dfree(c->d_mu1R4); dfree(c->d_s11R4);
     dfree(c->d_orig); dfree(c->d_tile_pal); dfree(c->d_colors); dfree(c->d_map); dfree(c->d_pack); dfree(c->d_packT); dfree(c->d_eotf); dfree(c->d_lab_eotf);
     dfree(c->d_pal_rgb8); dfree(c->d_pal_lin); dfree(c->d_pal_xyb); dfree(c->d_pal_lab); dfree(c->d_lin0); dfree(c->d_img1); dfree(c->d_img1T); dfree(c->d_mu1); dfree(c->d_s11);
+    dfree(c->d_bestmaps_all); dfree(c->d_bestrecs_all); dfree(c->d_skip);
     dfree(c->d_labpx); dfree(c->d_labpxT); dfree(c->d_work); dfree(c->d_cand_tab); dfree(c->d_cand_lab); dfree(c->d_part); dfree(c->d_maps); dfree(c->d_mapsT);
     dfree(c->d_cand); dfree(c->d_cand_sel); dfree(c->d_errs); dfree(c->d_errs_sel); dfree(c->d_inc_err); dfree(c->d_last); dfree(c->d_scratch_err); dfree(c->d_dummy_cand);
     for (auto &L : c->extra) { if (L.stream) (void)hipStreamSynchronize(L.stream); dfree(L.d_mapsC4); dfree(L.d_mapsR4); dfree(L.d_work); dfree(L.d_cand_tab); dfree(L.d_cand_lab); dfree(L.d_part); dfree(L.d_maps); dfree(L.d_mapsT); if (L.done) (void)hipEventDestroy(L.done); if (L.stream) (void)hipStreamDestroy(L.stream); }
@@ -831,6 +856,7 @@ int32_t snesimage_step_begin(snesimage_ctx *c, uint32_t method, uint32_t palette
         // candidate j of the shard is global candidate shard_rank + j*shard_count
         CHECK(score_list(c, c->d_cand_sel, n_own, d_errors, (int)shard_count, (int)shard_rank, (int)palette, (int)index, nullptr));
     }
+    if (!n_own) c->best_valid = false;
     c->pend = true; c->pend_n = n; c->pend_sp = palette; c->pend_si = index; c->pend_method = method;
     return SNES_OK;
 }
@@ -856,7 +882,7 @@ int32_t snesimage_set_tile_palettes(snesimage_ctx *c, const uint8_t *in) {
     CHECK(set_device(c));
     HIPCHK(hipMemcpyAsync(c->d_tile_pal, in, 1024, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->pack_valid = false; c->inc_valid = false;
+    c->pack_valid = false; c->inc_valid = false; c->map_synced = false;
     return SNES_OK;
 }
 int32_t snesimage_get_palette_rgb5(snesimage_ctx *c, uint8_t *out) {
@@ -871,7 +897,7 @@ int32_t snesimage_set_palette_rgb5(snesimage_ctx *c, const uint8_t *in) {
     CHECK(set_device(c));
     HIPCHK(hipMemcpyAsync(c->d_colors, in, 3 * (size_t)c->ncol, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->tables_valid = false; c->pack_valid = false; c->inc_valid = false;
+    c->tables_valid = false; c->pack_valid = false; c->inc_valid = false; c->map_synced = false;
     return SNES_OK;
 }
 int32_t snesimage_get_palette_u16(snesimage_ctx *c, uint16_t *out) {
@@ -894,7 +920,7 @@ int32_t snesimage_set_palette_map(snesimage_ctx *c, const uint8_t *in) {
     CHECK(set_device(c));
     HIPCHK(hipMemcpyAsync(c->d_map, in, c->npx, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->pack_valid = false; c->inc_valid = false;
+    c->pack_valid = false; c->inc_valid = false; c->map_synced = false;
     return SNES_OK;
 }
 

@@ -49,6 +49,7 @@ struct DitherParams {
     const uint8_t *orig; const uint8_t *tile_pal; const uint32_t *pal_rgb8; const float *pal_lab; const float *cand_tab; const float *cand_lab; const float *lab_eotf;
     uint8_t *maps, *mapsC4; // row-major and the column-blocked layout of kernels_fast.hpp (k_maps_relayout derives the others)
     int W, H, sub_size, ncol; uint32_t slot_ci; int perceptual;
+    const int *skip; // optional device flag: nonzero = the map is already in place, leave at once
 };
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(128) void k_dither(DitherParams P) {
     __shared__ float s_eotf[PERC ? 256 : 1];
     __shared__ double ring[128][4][3];
     __shared__ uint8_t s_tile[1024];
+    if (P.skip && *P.skip) return;
     const int j = threadIdx.x;
     const int cand = blockIdx.x;
     constexpr int W = 256; // snesimage_create admits no other width; a constant keeps the per-step index arithmetic to shifts
@@ -208,6 +210,53 @@ __global__ __launch_bounds__(128) void k_dither(DitherParams P) {
     }
 }
 
+// ---- the winner's map -----------------------------------------------------------------------------------
+// Each lane remembers the first-lowest error it has scored in the current candidate list and that candidate's map.
+struct BestRec { double err; int k; int pad; };
+struct StepResult { double error; int32_t best_k; uint8_t rgb5[3]; uint8_t changed; };
+__global__ void k_reset_best(BestRec *__restrict__ recs, int n) {
+    if ((int)threadIdx.x < n) { recs[threadIdx.x].err = __longlong_as_double(0x7ff0000000000000ll); recs[threadIdx.x].k = -1; }
+}
+// errors of this chunk sit at errors[off + i*stride], i < nc; that position is the candidate's index in the step's list
+__global__ __launch_bounds__(1024) void k_keep_best(const double *__restrict__ errors, int stride, int off, int nc, const uint8_t *__restrict__ maps, int npx, BestRec *__restrict__ rec,
+                                                   uint8_t *__restrict__ bestmap) {
+    __shared__ double s_e[1024];
+    __shared__ int s_i[1024];
+    const int t = threadIdx.x;
+    double be = __longlong_as_double(0x7ff0000000000000ll); int bi = 0x7fffffff;
+    for (int i = t; i < nc; i += 1024) { const double e = errors[off + (size_t)i * stride]; if (e < be) { be = e; bi = i; } }
+    s_e[t] = be; s_i[t] = bi;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if (t < st) {
+            const double e2 = s_e[t + st]; const int i2 = s_i[t + st];
+            if (e2 < s_e[t] || (e2 == s_e[t] && i2 < s_i[t])) { s_e[t] = e2; s_i[t] = i2; }
+        }
+        __syncthreads();
+    }
+    be = s_e[0]; bi = s_i[0];
+    if (bi == 0x7fffffff || !(be < rec->err)) return; // chunks reach a lane in ascending order: strict < keeps the first index
+    const uint4 *src = reinterpret_cast<const uint4 *>(maps + (size_t)bi * npx);
+    uint4 *dst = reinterpret_cast<uint4 *>(bestmap);
+    for (int i = t; i < npx / 16; i += 1024) dst[i] = src[i];
+    __syncthreads(); // every thread has compared against the old record
+    if (t == 0) { rec->err = be; rec->k = off + bi * stride; }
+}
+// After k_commit: if the winner was scored here, its map becomes the image's map and *skip = 1 (the re-dither is void);
+// likewise when nothing was accepted and the stored map already belongs to the palette.
+__global__ __launch_bounds__(1024) void k_take_best_map(const StepResult *__restrict__ last, const BestRec *__restrict__ recs, int nrec, const uint8_t *__restrict__ bestmaps, int npx,
+                                                       int map_synced, uint8_t *__restrict__ map, int *__restrict__ skip) {
+    const int best_k = last->best_k;
+    int lane = -1;
+    if (best_k >= 0) for (int r = 0; r < nrec; r++) if (recs[r].k == best_k) lane = r;
+    if (lane >= 0) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(bestmaps + (size_t)lane * npx);
+        uint4 *dst = reinterpret_cast<uint4 *>(map);
+        for (int i = threadIdx.x; i < npx / 16; i += 1024) dst[i] = src[i];
+    }
+    if (threadIdx.x == 0) *skip = (lane >= 0 || (best_k < 0 && map_synced)) ? 1 : 0;
+}
+
 // Row-blocked (R4: [y/4][x][y%4]) and, on request, transposed ([x][y]) copies of the row-major per-candidate maps.
 // Both hold the same word — rows 4q..4q+3 of column x — at different places.
 __global__ __launch_bounds__(256) void k_maps_relayout(const uint8_t *__restrict__ maps, int W, int H, uint32_t *__restrict__ r4, uint32_t *__restrict__ mT) {
@@ -222,7 +271,6 @@ __global__ __launch_bounds__(256) void k_maps_relayout(const uint8_t *__restrict
 }
 
 // ---- optimizer step: candidates and commit -------------------------------------------------------
-struct StepResult { double error; int32_t best_k; uint8_t rgb5[3]; uint8_t changed; };
 
 __device__ __forceinline__ unsigned long long dev_mix64(unsigned long long z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;

@@ -291,6 +291,55 @@ def test_split_phase_step_equals_plain_step(S, O, img256):
     ref.close()
 
 
+def test_dither_commit_takes_winner_map(S, O):
+    """With dither the commit adopts the winning candidate's map (kept per launch lane) instead of dithering again;
+    more chunks than lanes, a ragged last chunk, and a winner scored on another shard (fallback: dither again)."""
+    from hipmem import DeviceArray
+    from snesimage_amd.synth import synth_image
+    img = synth_image(0x5EED0007, 256, 32, 1)
+    g, o = pair(S, O, img, 2, 15, dither=True)
+    o.initialize_tiles()
+    o.recalculate_palettes()
+    sync_state(g, o)
+    g.optimize()
+    o.optimize()
+    g.set_chunk(4)
+    for i, (p, idx) in enumerate([(0, 0), (1, 7), (0, 0), (1, 14)]):
+        eg, bg = g.step(S.METHOD_RANDOM, p, idx, 0, 9, i, 18)
+        eo, bo = o.step(0, p, idx, 0, 9, i, 18)
+        assert np.array_equal(bg, bo) and rel(eg, eo) < REL_ERR
+        assert np.array_equal(g.palette_map, o.palette_map), i
+    # a palette set behind the optimizer's back: the stored map is stale, so an unchanged step must dither again
+    pal = o.palette.copy(); pal[3] = (pal[3] + 5) % 32
+    g.palette = pal; o.palette = pal
+    eg, bg = g.step(S.METHOD_CHANNEL, 0, 5, 1, 9, 100, 0)
+    eo, bo = o.step(1, 0, 5, 1, 9, 100, 0)
+    assert np.array_equal(bg, bo) and np.array_equal(g.palette_map, o.palette_map)
+    # two shards of one step: each commits the same winner, only one of them scored it
+    shards = []
+    for _ in range(2):
+        s = S.OptimizedImage(img, 2, 15, dither=True)
+        s.tile_palettes = g.tile_palettes
+        s.palette = g.palette
+        s.optimize()
+        shards.append(s)
+    for i, (p, idx) in enumerate([(1, 3), (0, 9)]):
+        e_ref, b_ref = g.step(S.METHOD_RANDOM, p, idx, 0, 11, 200 + i, 10)
+        bufs = [DeviceArray(10, np.float64, fill=0) for _ in range(2)]
+        for r, s in enumerate(shards):
+            s.step_begin(S.METHOD_RANDOM, p, idx, 0, 11, 200 + i, 10, r, 2, bufs[r].ptr)
+            s.sync()
+        red = DeviceArray.from_numpy(np.minimum(bufs[0].numpy(), bufs[1].numpy()))
+        for s in shards:
+            s.step_commit(red.ptr)
+            e, b, _ = s.last_step()
+            assert e == e_ref and np.array_equal(b, b_ref)
+            assert np.array_equal(s.palette_map, g.palette_map)
+    for s in shards:
+        s.close()
+    g.close()
+
+
 # ---- size-independent properties at BASELINE's full size ---------------------------------------------
 def test_exact_reconstruction_scores_zero(S):
     rng = np.random.default_rng(21)
