@@ -7,11 +7,13 @@ best by the reference's rule and commit it (lib.rs:236-237).  The slot sequence 
 scheduler (lib.rs:881-933).  Inputs (image, tile map, palette, source-side pyramid) are resident in
 HBM before the timed region starts.
 
-    python bench.py --gpus N --steps K --warmup W [--batch B] [--config rgb|perceptual|dither]
+    python bench.py --gpus N --steps K --warmup W [--batch B] [--config rgb|perceptual|dither|images]
 
 N > 1 is launched by the driver as one process per GPU (torch.distributed.run); ranks shard the
 candidates of every step and exchange ONE RCCL min-all-reduce per step.  `--scaling weak` (default)
 keeps B candidates per GPU per step (N*B per step in total); `--scaling strong` shards a fixed B.
+`--config images` is the throughput mode: --images independent 256x256 images per GPU, each
+stepped with the reference's 64 candidates per call, no collective; a step is one optimizer call on every image.
 Rank 0 prints one JSON line.
 """
 import argparse
@@ -64,18 +66,79 @@ def cpu_baseline(img, sub_count, sub_size, flags, tile_palettes, palette, budget
                       "with the source side recomputed per candidate (as lib.rs:506-525)" % (per_thread, cores)}
 
 
+def bench_images(args, torch, dist, S, world, rank, local_rank, device, force_dist):
+    """Throughput mode: this rank's block of the world*images synthetic images, no exchange between ranks."""
+    from snesimage_amd.throughput import ImageBatch, shard_images
+
+    sub_count, sub_size = 8, 15
+    mine = shard_images(args.images * world, rank, world)
+    batch = ImageBatch.synthetic(mine, sub_count, sub_size, device=local_rank, candidates=args.batch, host_threads=args.host_threads)
+    batch.initialize()  # untimed: TileAssignment + Clustering of every image
+    batch.run(args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    batch.run(args.steps)  # ends with a sync of every image's stream
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    errs = batch.errors()
+    if rank == 0:
+        total = len(mine) * world * args.batch * args.steps
+        value = total / dt
+        out = {
+            "metric": "candidate palettes scored/sec", "value": value, "unit": "candidates/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "throughput mode: %d synthetic 256x256 RGBA8 images per GPU (seeds 0x5EED0000+i), 8 subpalettes x 15, "
+                                   "RGB redmean distance, no dither, %d candidates per optimizer call per image, one call on every "
+                                   "image per step, remap + SSIMULACRA2 per candidate, no collective" % (len(mine), args.batch),
+                       "images_per_gpu": len(mine), "batch": args.batch, "config": "images", "host_threads": args.host_threads,
+                       "mean_final_error": sum(errs) / len(errs)},
+            "roofline": {"bound": "hbm", "kernel": "pipeline (kernels of different images overlap; no per-kernel timing in this mode)",
+                         "achieved": value / world * ALGO_BYTES_PER_CANDIDATE / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": value / world * ALGO_BYTES_PER_CANDIDATE / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_candidate": ALGO_BYTES_PER_CANDIDATE},
+        }
+        print(json.dumps(out), flush=True)
+    batch.close()
+    if world > 1 or force_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=4096,
-                    help="candidates per optimizer call per GPU (weak) or in total (strong); the reference draws 64 (lib.rs:205)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="candidates per optimizer call per GPU (weak) or in total (strong); default 4096, and the reference's 64 "
+                         "(lib.rs:205) for --config images")
+    ap.add_argument("--images", type=int, default=128, help="--config images: images per GPU (1,024 over 8 GPUs)")
+    ap.add_argument("--host-threads", type=int, default=8, help="--config images: host threads enqueueing optimizer calls")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--config", choices=["rgb", "perceptual", "dither"], default="rgb")
+    ap.add_argument("--config", choices=["rgb", "perceptual", "dither", "images"], default="rgb")
     ap.add_argument("--chunk", type=int, default=0, help="candidates per launch group (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if not args.batch:
+        args.batch = 64 if args.config == "images" else 4096
+    if args.config == "images":
+        # one launch lane per image and the base image's sweeps on the image's own stream (the concurrency comes from the
+        # images; per-image side streams only add cross-queue waits), the group-sparse path from 32 candidates up, and more
+        # hardware queues than the runtime's default four for the per-image streams
+        os.environ.setdefault("SNES_LANES", "1")
+        os.environ.setdefault("SNES_BASE_STREAM", "0")
+        os.environ.setdefault("SNES_SPARSE_MIN", "32")
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
     import torch
     import torch.distributed as dist
@@ -101,6 +164,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     sub_count, sub_size = 8, 15
+    if args.config == "images":
+        return bench_images(args, torch, dist, S, world, rank, local_rank, device, force_dist)
     flags = {"rgb": 0, "perceptual": S.PERCEPTUAL, "dither": S.DITHER}[args.config]
     img = synth_image()
     image = S.OptimizedImage(img, sub_count, sub_size, dither=bool(flags & S.DITHER), perceptual=bool(flags & S.PERCEPTUAL),

@@ -124,7 +124,7 @@ struct snesimage_ctx {
     std::vector<Lane> extra; uint32_t nlanes = 2; hipEvent_t ev_ready = nullptr;
     // Row-sparse scoring (kernels_sparse.hpp): one storage array for every lane's candidates plus the base image B
     struct Sparse {
-        bool enabled = false; uint32_t min_n = 128; uint32_t cap = 0; // cap = candidates per lane the arrays were sized for
+        bool enabled = false, side = true; uint32_t min_n = 128; uint32_t cap = 0; // cap = candidates per lane the arrays were sized for
         SparseGeom S{};
         float *store = nullptr, *cand_tab = nullptr, *cand_lab = nullptr, *ckf = nullptr; uint32_t *bitmap = nullptr; double *cka = nullptr, *part = nullptr;
         CandMeta *meta = nullptr; unsigned int *items = nullptr; int *item_count = nullptr; long long item_stride = 0;
@@ -403,7 +403,7 @@ int32_t sparse_alloc(snesimage_ctx *c) {
     HIPCHK(hipMalloc(&sp.part, sizeof(double) * ncap * kMaxScales * 18));
     HIPCHK(hipMalloc(&sp.meta, sizeof(CandMeta) * ncap));
     HIPCHK(hipMalloc(&sp.items, sizeof(unsigned int) * (size_t)sp.item_stride * kMaxScales * (c->nlanes + 1)));
-    if (!sp.base_stream) {
+    if (!sp.base_stream && sp.side) {
         int prio_lo = 0, prio_hi = 0; // B's sweeps are the critical path of a step: give them the highest stream priority
         HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         HIPCHK(hipStreamCreateWithPriority(&sp.base_stream, hipStreamNonBlocking, prio_hi));
@@ -445,12 +445,14 @@ int32_t sparse_base_pass(snesimage_ctx *c) {
         hipLaunchKernelGGL(k_base_down, dim3((unsigned)((G.W / 32) * (G.H / 32))), dim3(256), 0, c->stream, P); // B: every row of every scale
         // B's H and V passes are long single-image sweeps (latency-bound); they run on their own stream beside the
         // candidates' scan / downscale / H pass, which only need B's linear-RGB rows.  The candidates' V pass waits for them.
-        HIPCHK(hipEventRecord(sp.ev_base_in, c->stream));
-        HIPCHK(hipStreamWaitEvent(sp.base_stream, sp.ev_base_in, 0));
-        hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((G.sh[0] / 4 * 3 + 15) / 16), (unsigned)G.nscales), dim3(64), 0, sp.base_stream, P);
-        hipLaunchKernelGGL(k_sparse_v, dim3(3, (unsigned)G.nscales), dim3(256), 0, sp.base_stream, P);
+        // (SNES_BASE_STREAM=0 keeps them on the context's stream: with many contexts on one device the extra streams only
+        // add cross-queue waits.)
+        hipStream_t bs = sp.side ? sp.base_stream : c->stream;
+        if (sp.side) { HIPCHK(hipEventRecord(sp.ev_base_in, c->stream)); HIPCHK(hipStreamWaitEvent(bs, sp.ev_base_in, 0)); }
+        hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((G.sh[0] / 4 * 3 + 15) / 16), (unsigned)G.nscales), dim3(64), 0, bs, P);
+        hipLaunchKernelGGL(k_sparse_v, dim3(3, (unsigned)G.nscales), dim3(256), 0, bs, P);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(sp.ev_base_done, sp.base_stream));
+        if (sp.side) HIPCHK(hipEventRecord(sp.ev_base_done, bs));
         sp.plist_valid = true;
     }
     return SNES_OK;
@@ -474,7 +476,7 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[1], stream));
     { size_t gx = ((size_t)nc * (G.sh[0] / 4) * 3 + 15) / 16; if (gx > 2048) gx = 2048; // grid-stride over the item quads
       hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)gx, (unsigned)G.nscales), dim3(64), 0, stream, P); }
-    HIPCHK(hipStreamWaitEvent(stream, sp.ev_base_done, 0)); // checkpoints and H output of B
+    if (sp.side || stream != c->stream) HIPCHK(hipStreamWaitEvent(stream, sp.side ? sp.ev_base_done : c->ev_ready, 0)); // checkpoints and H output of B
     if (c->timing) { HIPCHK(hipEventRecord(tr.ev[2], stream)); HIPCHK(hipEventRecord(tr.ev[3], stream)); }
     hipLaunchKernelGGL(k_sparse_v, dim3(nc * 3, (unsigned)G.nscales), dim3(256), 0, stream, P);
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[4], stream));
@@ -652,6 +654,7 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     if (const char *e = getenv("SNES_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->nlanes = (uint32_t)v; }
     c->sp.enabled = (h == 256) && !c->dither; // the group-sparse path covers the no-dither remap (RGB keys or CIEDE2000) at the full size
     if (const char *e = getenv("SNES_SPARSE")) c->sp.enabled = c->sp.enabled && atoi(e) != 0;
+    if (const char *e = getenv("SNES_BASE_STREAM")) c->sp.side = atoi(e) != 0;
     if (const char *e = getenv("SNES_SPARSE_MIN")) { int v = atoi(e); if (v >= 1) c->sp.min_n = (uint32_t)v; }
     Geom &G = c->G;
     G.W = (int)w; G.H = (int)h; G.nscales = 0;

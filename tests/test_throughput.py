@@ -1,0 +1,44 @@
+"""Throughput mode: image sharding on the CPU, concurrent contexts on the GPU."""
+import numpy as np
+import pytest
+
+from snesimage_amd.throughput import shard_images
+
+
+@pytest.mark.parametrize("n,world", [(1024, 8), (1024, 1), (10, 4), (3, 8), (0, 2), (129, 2)])
+def test_shard_images_is_a_partition(n, world):
+    blocks = [shard_images(n, r, world) for r in range(world)]
+    flat = [i for b in blocks for i in b]
+    assert flat == list(range(n))                      # disjoint, complete, contiguous and in rank order
+    sizes = [len(b) for b in blocks]
+    assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    with pytest.raises(ValueError):
+        shard_images(n, world, world)
+
+
+@pytest.mark.gpu
+def test_concurrent_images_equal_one_at_a_time():
+    """Optimizer calls of several images enqueued side by side from several host threads give, for every image, exactly
+    the state that stepping that image alone gives."""
+    import snesimage_amd as S
+    from snesimage_amd.synth import synth_image
+    from snesimage_amd.throughput import IMAGE_SEED0, ImageBatch
+
+    ids = [5, 6, 7, 900]
+    batch = ImageBatch.synthetic(ids, 4, 7, candidates=24, host_threads=3)
+    batch.initialize()
+    batch.run(3)
+    batch.run(4)  # the schedule continues where the first run stopped
+    sched = S.schedule(4, 7, 7)
+    for pos, gid in enumerate(ids):
+        solo = S.OptimizedImage(synth_image(IMAGE_SEED0 + gid), 4, 7)
+        solo.initialize_tiles()
+        solo.recalculate_palettes()
+        for j, (method, p, idx, ch, _) in enumerate(sched):
+            e, _ = solo.step(method, p, idx, ch, 1 + gid, j, 24 if method == S.METHOD_RANDOM else 0)
+        img = batch.images[pos]
+        assert np.array_equal(img.palette, solo.palette) and np.array_equal(img.palette_map, solo.palette_map)
+        assert np.array_equal(img.tile_palettes, solo.tile_palettes)
+        assert batch.errors()[pos] == e
+        solo.close()
+    batch.close()
