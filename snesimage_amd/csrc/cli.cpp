@@ -6,7 +6,9 @@
 // --calls optimizer calls in the reference's slot order (src/lib.rs:881-933) -> write the JSON.
 // Extra flags exist only because the reference is interactive and unseeded: --seed, --calls,
 // --candidates, --device, --tile-palettes FILE (1024 bytes, replaces the mouse clicks of
-// src/lib.rs:1005-1017).  The source image is a raw RGBA8 file of 256*H*4 bytes, or `synth:SEED`.
+// src/lib.rs:1005-1017), --preview FILE.png (source | result side by side, the picture the SDL window of
+// src/lib.rs:937-960 shows).  The source image is a PNG (png_io.hpp restates `image::open(..).into_rgba8()`,
+// src/lib.rs:836, for that format), a raw RGBA8 file of 256*H*4 bytes, or `synth:SEED`.
 // The host language the north star asks for is Rust; no Rust toolchain exists in this image, so the
 // driver is C++ over the same extern "C" surface a Rust crate would bind.
 #include "../../include/snesimage_hip.h"
@@ -18,6 +20,8 @@
 #include <ctime>
 #include <string>
 #include <vector>
+
+#include "png_io.hpp"
 
 namespace {
 
@@ -46,12 +50,13 @@ std::string fmt_f64(double v) { // Rust's `{}` for f64: shortest representation 
 void usage() {
     fprintf(stderr,
             "Usage: snesimage_cli [OPTIONS] <SOURCE_FILENAME> <TARGET_FILENAME>\n\n"
-            "Arguments:\n  <SOURCE_FILENAME>  raw RGBA8 file (256 x H x 4 bytes) or synth:SEED\n  <TARGET_FILENAME>  JSON output\n\n"
+            "Arguments:\n  <SOURCE_FILENAME>  PNG image, raw RGBA8 file (256 x H x 4 bytes) or synth:SEED\n  <TARGET_FILENAME>  JSON output\n\n"
             "Options:\n  -c, --subpalette-count <N>  [default: 1]\n  -s, --subpalette-size <N>   [default: 7]\n"
             "  -d, --dither\n      --perceptual-palettes\n      --nes\n"
             "      --calls <N>          optimizer calls to run [default: 0]\n      --candidates <N>     random candidates per call [default: 64]\n"
             "      --seed <N>           candidate RNG seed [default: 1]\n      --device <N>         HIP device [default: 0]\n"
-            "      --tile-palettes <F>  1024-byte tile->subpalette override\n  -h, --help\n  -V, --version\n");
+            "      --tile-palettes <F>  1024-byte tile->subpalette override\n      --preview <F>        write source | result as a PNG\n"
+            "      --decode-only        write the decoded source as raw RGBA8 to <TARGET_FILENAME> and stop (no GPU)\n  -h, --help\n  -V, --version\n");
 }
 void synth(uint64_t seed, uint32_t w, uint32_t h, std::vector<uint8_t> &out) {
     out.resize((size_t)w * h * 4);
@@ -74,7 +79,8 @@ int main(int argc, char **argv) {
     uint32_t count = 1, size = 7, flags = 0, calls = 0, ncand = 64; // src/config.rs:13-18 defaults
     uint64_t seed = 1;
     int device = 0;
-    std::string tile_file;
+    std::string tile_file, preview_file;
+    bool decode_only = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto need = [&](const char *name) -> const char * { if (i + 1 >= argc) { fprintf(stderr, "error: a value is required for '%s'\n", name); exit(2); } return argv[++i]; };
@@ -88,6 +94,8 @@ int main(int argc, char **argv) {
         else if (a == "--seed") seed = strtoull(need("--seed"), nullptr, 0);
         else if (a == "--device") device = atoi(need("--device"));
         else if (a == "--tile-palettes") tile_file = need("--tile-palettes");
+        else if (a == "--preview") preview_file = need("--preview");
+        else if (a == "--decode-only") decode_only = true;
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else if (a == "-V" || a == "--version") { printf("snesimage 0.1.1 (%s)\n", snesimage_version()); return 0; }
         else if (!a.empty() && a[0] == '-' && a != "-") { fprintf(stderr, "error: unexpected argument '%s' found\n", a.c_str()); usage(); return 2; }
@@ -104,11 +112,28 @@ int main(int argc, char **argv) {
         FILE *f = fopen(source.c_str(), "rb");
         if (!f) die("No such file or directory: " + source);
         fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
-        if (n <= 0 || n % (256 * 4) != 0) { fclose(f); die("Image size must be 256x256"); } // src/lib.rs:838-840
-        h = (uint32_t)(n / (256 * 4));
-        rgba.resize((size_t)n);
-        if (fread(rgba.data(), 1, (size_t)n, f) != (size_t)n) { fclose(f); die("short read on " + source); }
+        std::vector<uint8_t> file(n > 0 ? (size_t)n : 0);
+        if (n <= 0 || fread(file.data(), 1, (size_t)n, f) != (size_t)n) { fclose(f); die("short read on " + source); }
         fclose(f);
+        if (snes_png::is_png(file.data(), file.size())) {
+            std::string err;
+            if (!snes_png::decode(file.data(), file.size(), w, h, rgba, err)) die("Format error decoding Png: " + err);
+            // src/lib.rs:838-840 tests `width != 256 && height != 256` and then indexes tiles with a hard-coded 32;
+            // this build admits what that arithmetic handles: 256 wide, and the height the library accepts
+            if (w != 256) die("Image size must be 256x256");
+        } else {
+            if (n % (256 * 4) != 0) die("Image size must be 256x256"); // src/lib.rs:838-840
+            h = (uint32_t)(n / (256 * 4));
+            rgba.swap(file);
+        }
+    }
+    if (decode_only) {
+        FILE *f = fopen(target.c_str(), "wb");
+        if (!f) die("cannot create " + target);
+        fwrite(rgba.data(), 1, rgba.size(), f);
+        fclose(f);
+        printf("%u %u\n", w, h);
+        return 0;
     }
     snesimage_ctx *ctx = nullptr;
     if (snesimage_create(rgba.data(), w, h, count, size, flags, device, &ctx) != 0) die(snesimage_last_error());
@@ -151,6 +176,20 @@ int main(int argc, char **argv) {
     if (!f) die("cannot create " + target);
     fwrite(json.data(), 1, (size_t)need - 1, f);
     fclose(f);
+    if (!preview_file.empty()) { // left: source, right: as_rgba() of the result (src/lib.rs:940-957)
+        std::vector<uint8_t> result((size_t)w * h * 4), both((size_t)2 * w * h * 4), png;
+        if (snesimage_as_rgba(ctx, result.data()) != 0) die(snesimage_last_error());
+        for (uint32_t y = 0; y < h; y++) {
+            memcpy(&both[(size_t)y * 2 * w * 4], &rgba[(size_t)y * w * 4], (size_t)w * 4);
+            memcpy(&both[((size_t)y * 2 + 1) * w * 4], &result[(size_t)y * w * 4], (size_t)w * 4);
+        }
+        if (!snes_png::encode_rgba(2 * w, h, both.data(), png)) die("cannot encode " + preview_file);
+        FILE *pf = fopen(preview_file.c_str(), "wb");
+        if (!pf) die("cannot create " + preview_file);
+        fwrite(png.data(), 1, png.size(), pf);
+        fclose(pf);
+        log_info("Wrote preview to " + preview_file);
+    }
     snesimage_destroy(ctx);
     return 0;
 }

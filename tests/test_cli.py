@@ -72,3 +72,57 @@ def test_cli_end_to_end_matches_oracle(tmp_path, O, extra, count, size, flags):
     out2 = tmp_path / "out2.json"
     r2 = run("synth:%d" % seed_img, str(out2), "-c", str(count), "-s", str(size), "--calls", str(calls), "--candidates", str(ncand), "--seed", "5", *extra)
     assert r2.returncode == 0 and out2.read_text() == text
+
+
+def read_plain_png(data):
+    """Decoder for what the driver writes: RGBA8, filter 0 on every row."""
+    import struct
+    import zlib
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(data):
+        n, kind = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        assert zlib.crc32(kind + body) & 0xFFFFFFFF == struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0]
+        if kind == b"IHDR":
+            w, h, depth, ctype = struct.unpack(">IIBB", body[:10])
+            assert (depth, ctype) == (8, 6)
+        elif kind == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 4 * w)
+    assert not raw[:, 0].any()
+    return raw[:, 1:].reshape(h, w, 4)
+
+
+@pytest.mark.gpu
+def test_cli_png_source_and_preview(tmp_path):
+    """A PNG source gives the JSON of the same pixels as a raw file; --preview shows source | as_rgba() of the result."""
+    from snesimage_amd.synth import synth_image
+    from test_png_io import encode_png
+    img = synth_image(0x5EED0004, 256, 64, 1)  # with a transparent square
+    raw, png = tmp_path / "in.rgba", tmp_path / "in.png"
+    raw.write_bytes(img.tobytes())
+    png.write_bytes(encode_png(img.astype(np.int64), 6, 8, interlace=True, seed=4))
+    args = ["-c", "4", "-s", "7", "--calls", "5", "--candidates", "10", "--seed", "3"]
+    r1 = run(str(raw), str(tmp_path / "a.json"), *args)
+    r2 = run(str(png), str(tmp_path / "b.json"), *args, "--preview", str(tmp_path / "p.png"))
+    assert r1.returncode == 0 and r2.returncode == 0, r2.stdout + r2.stderr
+    assert (tmp_path / "a.json").read_text() == (tmp_path / "b.json").read_text()
+    both = read_plain_png((tmp_path / "p.png").read_bytes())
+    assert both.shape == (64, 512, 4) and np.array_equal(both[:, :256], img)
+    # the right half is the reconstruction of the JSON: tiles -> palette -> 8-bit expansion (lib.rs:550-577, 662-669)
+    doc = json.loads((tmp_path / "b.json").read_text())
+    pal = np.array(doc["palette"], np.uint32).reshape(-1, 16)
+    tiles = np.array(doc["tiles"]).reshape(-1, 8, 8)
+    tp = np.array(doc["tile_palettes"])
+    want = np.zeros((64, 256, 4), np.uint8)
+    for t in range(8 * 32):
+        ty, tx = divmod(t, 32)
+        v = tiles[t]
+        c = pal[tp[t]][v]
+        r5, g5, b5 = c & 31, (c >> 5) & 31, (c >> 10) & 31
+        blk = np.stack([r5 * 8 + r5 // 4, g5 * 8 + g5 // 4, b5 * 8 + b5 // 4, np.full_like(r5, 255)], -1).astype(np.uint8)
+        blk[v == 0] = 0
+        want[ty * 8:ty * 8 + 8, tx * 8:tx * 8 + 8] = blk
+    assert np.array_equal(both[:, 256:], want)
