@@ -70,6 +70,11 @@ int32_t snesimage_score_candidates(snesimage_ctx *ctx, uint32_t palette, uint32_
 int32_t snesimage_score_candidates_device(snesimage_ctx *ctx, uint32_t palette, uint32_t index,
                                           const uint8_t *d_rgb5, uint32_t n, double *d_errors,
                                           uint8_t *d_maps_out);
+/* The remap alone — the optimize() of lib.rs:210-213 for each candidate, without its error():
+ * d_maps_out (device, n*w*h bytes) receives the palette_map each candidate would produce.
+ * Device pointers, asynchronous on the context's stream. */
+int32_t snesimage_remap_candidates_device(snesimage_ctx *ctx, uint32_t palette, uint32_t index,
+                                          const uint8_t *d_rgb5, uint32_t n, uint8_t *d_maps_out);
 
 /* One optimizer call — optimize_palette_entry_{random,channel,nes} (lib.rs:191-328) followed by
  * lib.rs:906-910.  Random candidates come from the counter RNG keyed (seed, step_id);

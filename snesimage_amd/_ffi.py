@@ -32,6 +32,7 @@ SIGNATURES = [
     ("snesimage_score_candidates", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, _u8p, C.c_uint32, _f64p]),
     ("snesimage_score_candidates_device", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
                                                       C.c_void_p, C.c_void_p]),
+    ("snesimage_remap_candidates_device", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]),
     ("snesimage_step", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                    C.c_uint64, C.c_uint32, _f64p, _u8p]),
     ("snesimage_step_async", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,

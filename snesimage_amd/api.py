@@ -130,6 +130,11 @@ class OptimizedImage:
         self._chk(self._L.snesimage_score_candidates_device(self._c, palette, index, C.c_void_p(d_rgb5_ptr), n,
                                                             C.c_void_p(d_errors_ptr), C.c_void_p(d_maps_ptr or 0)))
 
+    def remap_candidates_device(self, palette, index, d_rgb5_ptr, n, d_maps_ptr):
+        """optimize() of every candidate without error(): n palette_maps into device memory (asynchronous)."""
+        self._chk(self._L.snesimage_remap_candidates_device(self._c, palette, index, C.c_void_p(d_rgb5_ptr), n,
+                                                            C.c_void_p(d_maps_ptr)))
+
     def step(self, method, palette, index, channel=0, seed=1, step_id=0, n_random=0):
         """optimize_palette_entry_{random,channel,nes} + lib.rs:906-910 -> (error, best rgb5)."""
         err = C.c_double(0)

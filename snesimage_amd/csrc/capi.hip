@@ -810,6 +810,41 @@ int32_t snesimage_score_candidates(snesimage_ctx *c, uint32_t palette, uint32_t 
     return SNES_OK;
 }
 
+int32_t snesimage_remap_candidates_device(snesimage_ctx *c, uint32_t palette, uint32_t index, const uint8_t *d_rgb5, uint32_t n, uint8_t *d_maps_out) {
+    CHECK(check_slot(c, palette, index));
+    if (!d_rgb5 || !d_maps_out) return fail(SNES_ERR_ARG, "null pointer");
+    if (n == 0) return SNES_OK;
+    CHECK(set_device(c));
+    CHECK(alloc_workspace(c, c->chunk));
+    CHECK(ensure_tables(c));
+    if (c->perceptual) CHECK(ensure_source(c));
+    CHECK(prep_for_slot(c, (int)palette, (int)index));
+    const uint32_t slot_ci = palette * c->sub_size + index;
+    for (uint32_t c0 = 0; c0 < n; c0 += c->chunk) {
+        const uint32_t nc = (n - c0 < c->chunk) ? (n - c0) : c->chunk;
+        const uint8_t *rgb5 = d_rgb5 + 3 * (size_t)c0;
+        uint8_t *maps = d_maps_out + (size_t)c0 * c->npx;
+        hipLaunchKernelGGL(k_candidate_tables, dim3((nc + 63) / 64), dim3(64), 0, c->stream, rgb5, (int)nc, c->d_eotf, c->d_cand_tab);
+        if (c->perceptual) hipLaunchKernelGGL(k_candidate_lab, dim3((nc + 63) / 64), dim3(64), 0, c->stream, c->d_cand_tab, (int)nc, c->d_lab_eotf, c->d_cand_lab);
+        if (c->dither) {
+            hipLaunchKernelGGL(k_candidate_slot, dim3((nc + 63) / 64), dim3(64), 0, c->stream, c->d_cand_tab, (int)nc, slot_ci);
+            DitherParams Dp{};
+            Dp.orig = c->d_orig; Dp.tile_pal = c->d_tile_pal; Dp.pal_rgb8 = c->d_pal_rgb8; Dp.pal_lab = c->d_pal_lab; Dp.cand_tab = c->d_cand_tab; Dp.cand_lab = c->d_cand_lab;
+            Dp.lab_eotf = c->d_lab_eotf; Dp.maps = maps; Dp.mapsC4 = nullptr;
+            Dp.W = (int)c->W; Dp.H = (int)c->H; Dp.sub_size = (int)c->sub_size; Dp.ncol = c->ncol; Dp.slot_ci = slot_ci; Dp.perceptual = c->perceptual ? 1 : 0;
+            launch_dither(c, Dp, nc);
+        } else {
+            MapsParams M{}; M.pack = c->d_pack; M.cand_tab = c->d_cand_tab; M.cand_lab = c->d_cand_lab; M.labpx = c->d_labpx; M.maps = maps;
+            M.npx = (int)c->npx; M.ncol = c->ncol; M.sub_size = (int)c->sub_size; M.si = (int)index; M.ncand = (int)nc; M.perceptual = c->perceptual ? 1 : 0;
+            const dim3 grid((unsigned)((c->npx / 4 + 255) / 256), (nc + kRemapCands - 1) / kRemapCands);
+            if (c->perceptual) hipLaunchKernelGGL((k_remap4<true>), grid, dim3(256), 0, c->stream, M);
+            else hipLaunchKernelGGL((k_remap4<false>), grid, dim3(256), 0, c->stream, M);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return SNES_OK;
+}
+
 int32_t snesimage_step_async(snesimage_ctx *c, uint32_t method, uint32_t palette, uint32_t index, uint32_t channel, uint64_t seed, uint64_t step_id, uint32_t n_random) {
     CHECK(check_slot(c, palette, index));
     if (method > 2 || channel > 2) return fail(SNES_ERR_ARG, "bad method or channel");

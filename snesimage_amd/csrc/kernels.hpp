@@ -209,6 +209,39 @@ __global__ __launch_bounds__(256) void k_candidate_maps(MapsParams P) {
     P.maps[(size_t)cand * P.npx + px] = m;
 }
 
+// The remap on its own (optimize() of lib.rs:425-501 for every candidate, no scoring): thread = four consecutive pixels
+// whose pack words stay in registers while it walks kRemapCands candidates; one 32-bit store per candidate.  The pack
+// (512 KiB) is served from L2 after its first touch, so the HBM traffic of the kernel is the 64 KiB map per candidate.
+constexpr int kRemapCands = 8;
+template <bool PERC>
+__global__ __launch_bounds__(256) void k_remap4(MapsParams P) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q * 4 >= P.npx) return;
+    const uint4 a = reinterpret_cast<const uint4 *>(P.pack)[2 * (size_t)q], b = reinterpret_cast<const uint4 *>(P.pack)[2 * (size_t)q + 1];
+    const unsigned long long pk[4] = {((unsigned long long)a.y << 32) | a.x, ((unsigned long long)a.w << 32) | a.z, ((unsigned long long)b.y << 32) | b.x,
+                                      ((unsigned long long)b.w << 32) | b.z};
+    uint32_t m0[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t ci0 = (uint32_t)pk[i] >> 24;
+        m0[i] = ci0 == (uint32_t)P.ncol ? (uint32_t)P.si : (ci0 == (uint32_t)P.ncol + 1u ? 0u : ci0 % (uint32_t)P.sub_size);
+    }
+    const int c0 = blockIdx.y * kRemapCands;
+    for (int cc = 0; cc < kRemapCands && c0 + cc < P.ncand; cc++) {
+        const int cand = c0 + cc;
+        const uint32_t crgb = __float_as_uint(P.cand_tab[8 * (size_t)cand + 6]);
+        Lab cl; cl.l = cl.a = cl.b = 0.0f;
+        if (PERC) { cl.l = P.cand_lab[3 * cand]; cl.a = P.cand_lab[3 * cand + 1]; cl.b = P.cand_lab[3 * cand + 2]; }
+        uint32_t word = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t ci = resolve_ci<PERC>(pk[i], crgb, cl, PERC ? P.labpx + 3 * ((size_t)q * 4 + i) : nullptr, (uint32_t)P.ncol);
+            word |= (ci == (uint32_t)P.ncol ? (uint32_t)P.si : m0[i]) << (8 * i);
+        }
+        reinterpret_cast<uint32_t *>(P.maps + (size_t)cand * P.npx)[q] = word;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Downscale chain + XYB for scales 1..S-1 (ssimulacra2 downscale_by_2 in linear RGB, then
 // linear_rgb_to_xyb + make_positive_xyb).  One block = one 32x32 block of scale-0 pixels of one

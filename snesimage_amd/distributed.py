@@ -27,8 +27,11 @@ class HipShardScorer:
         self.image = image
         self.device = device
         self._buf = None
-        # run the library on torch's current stream so the collective is ordered behind the kernels
-        self.image.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        # The library and the collective share one explicit stream: `sharded_step` issues the all-reduce with this stream
+        # current, so RCCL is ordered behind the scoring kernels and the commit behind RCCL.  (torch's default stream has
+        # handle 0, which the library reads as "keep your own stream" — never hand it that one.)
+        self.stream = torch.cuda.Stream(device)
+        self.image.set_stream(self.stream.cuda_stream)
 
     def begin(self, method, palette, index, channel, seed, step_id, n_total, rank, world):
         n = n_total if method == api.METHOD_RANDOM else (32 if method == api.METHOD_CHANNEL else 56)
@@ -50,6 +53,11 @@ def sharded_step(scorer, method, palette, index, channel, seed, step_id, n_total
         rank, world = 0, 1
     errors = scorer.begin(method, palette, index, channel, seed, step_id, n_total, rank, world)
     if world > 1 or (dist.is_available() and dist.is_initialized()):
-        dist.all_reduce(errors, op=dist.ReduceOp.MIN, group=group)
+        stream = getattr(scorer, "stream", None)  # device scorers: the stream their kernels run on
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                dist.all_reduce(errors, op=dist.ReduceOp.MIN, group=group)
+        else:
+            dist.all_reduce(errors, op=dist.ReduceOp.MIN, group=group)
     scorer.commit(errors)
     return errors

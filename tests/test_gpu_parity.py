@@ -141,6 +141,12 @@ def test_score_candidates_parity_with_maps(S, O, img256_alpha, flags, slot, n):
     g.sync()
     assert np.array_equal(d_m.numpy(), mo)                   # indices bit-exact
     assert rel(d_e.numpy(), eo) < REL_ERR
+    d_r = DeviceArray((n, 256, 256), np.uint8, fill=7)       # the remap alone, in chunks that do not divide n
+    g.set_chunk(4)
+    g.remap_candidates_device(slot[0], slot[1], d_c.ptr, n, d_r.ptr)
+    g.sync()
+    g.set_chunk(1024)
+    assert np.array_equal(d_r.numpy(), mo)
     assert rel(g.score_candidates(slot[0], slot[1], cand), eo) < REL_ERR
     assert rel(eo[0], o.error()) == 0.0 and rel(g.score_candidates(slot[0], slot[1], cand[:1])[0], g.error()) == 0.0
     assert np.array_equal(g.palette, o.palette) and np.array_equal(g.palette_map, o.palette_map)  # state untouched
