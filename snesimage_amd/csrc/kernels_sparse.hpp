@@ -502,10 +502,20 @@ __global__ __launch_bounds__(64) void k_sparse_h(SparseParams P) {
 // block = 256 threads = 256/W_s (candidate, channel) pairs; thread = one image column.
 // Checkpoint record g (0 <= g <= H/4 + 1) of B: recurrence state before group iteration g (steps 4g-4..4g-1)
 // and pooling sums of rows < 4g-4; record H/4+1 holds the final sums.
-__global__ __launch_bounds__(256, 3) void k_sparse_v(SparseParams P) {
-    __shared__ float s_lut[3][256];
-    __shared__ double red[256][6];
+// Register budget: 128 VGPRs, i.e. four waves per SIMD (the kernel is bound by VALU issue and latency, and went
+// 1.12 -> 0.82 ms per 1,024 candidates from two to three waves).  Only the current and the next input group live in
+// registers; the trailing filter taps — rows 4g-10..4g-7, i.e. the second half of group g-3 and the first half of
+// group g-2 — come back from a per-thread LDS ring (read, then overwritten by the same thread: no barrier), and the
+// map inputs are loaded at the top of the iteration that consumes them, behind the twelve recurrence steps.
+__global__ __launch_bounds__(256, 4) void k_sparse_v(SparseParams P) {
+    __shared__ float s_lut[256];
     __shared__ short s_gslot[256];
+    // tails: xy halves two deep, zw halves three deep, [slot][plane][thread]; the pooling reduction reuses the space
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[(2 + 3) * 3 * 256 * sizeof(float2)];
+    float2 (*s_xy)[3][256] = reinterpret_cast<float2 (*)[3][256]>(s_raw);
+    float2 (*s_zw)[3][256] = reinterpret_cast<float2 (*)[3][256]>(s_raw + 2 * 3 * 256 * sizeof(float2));
+    double (*red)[6] = reinterpret_cast<double (*)[6]>(s_raw);
+    static_assert(sizeof(s_raw) >= 256 * 6 * sizeof(double), "reduction scratch must fit the tail ring");
     const Geom &G = P.G;
     const int s = blockIdx.y;
     if (s >= G.nscales) return;
@@ -516,15 +526,14 @@ __global__ __launch_bounds__(256, 3) void k_sparse_v(SparseParams P) {
     const int npairs = is_base ? 3 : P.ncand * 3;
     if ((int)blockIdx.x * ppw >= npairs) return;
     const bool S0 = (s == 0);
-    if (S0) {
-        for (int i = t; i < 3 * 256; i += 256) { int c = i >> 8, j = i & 255; s_lut[c][j] = (j < P.ncol + 2) ? P.pal_xyb[3 * j + c] : 0.0f; }
-        __syncthreads();
-    }
     const int ql = t / W, x = t - ql * W;
     const int pair_raw = blockIdx.x * ppw + ql;
     const bool active = pair_raw < npairs;
     const int pair = active ? pair_raw : 0;
     const int k = is_base ? P.base : P.k0 + pair / 3, ch = pair % 3;
+    if (S0) { // W = 256: the block is one (candidate, channel) pair, so one channel of the XYB table is enough
+        s_lut[t] = (t < P.ncol + 2) ? P.pal_xyb[3 * t + ch] : 0.0f;
+    }
     const size_t ns = (size_t)W * H;
     const int H4 = H >> 2;
     const CandMeta *M = P.meta + k;
@@ -543,7 +552,6 @@ __global__ __launch_bounds__(256, 3) void k_sparse_v(SparseParams P) {
     const float cand_v = is_base ? 0.0f : P.cand_tab[8 * (size_t)k + 3 + ch];
     const uint32_t crgb = is_base ? 0u : __float_as_uint(P.cand_tab[8 * (size_t)k + 6]);
     const uint32_t never = is_base ? 0u : 0xffffffffu;
-    const float *lut = s_lut[ch];
     const float *mine = P.store + (size_t)k * P.S.cand_stride;
     const float *basep = P.store + (size_t)P.base * P.S.cand_stride;
     // hout of group g, plane p: float4 index (p*W) + ((x>>6)<<6) + (x&63) inside the group's 9*W float4s
@@ -581,120 +589,121 @@ __global__ __launch_bounds__(256, 3) void k_sparse_v(SparseParams P) {
 #pragma unroll
         for (int q = 0; q < 6; q++) acc[q] = ca[(size_t)q * W];
     }
-    // ring: groups gs-3 .. gs-1 come from B (they precede the first changed group)
-    float4 ring[3][5];
-#pragma unroll
-    for (int p = 0; p < 3; p++)
-#pragma unroll
-        for (int a = 0; a < 5; a++) ring[p][a] = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto hload = [&](int g, int p) -> float4 { // group g of plane p: the candidate's if it changed, else B's
-        const short sl = gslot[g];
-        return sl >= 0 ? hm[(size_t)sl * 9 * W + (size_t)p * W] : hb[(size_t)g * 9 * W + (size_t)p * W];
+    // Offsets stay 32-bit and come from 24-bit multiplies (groups <= 64, 9W <= 2,304 float4s): the 64-bit
+    // multiplies of plain size_t indexing were a fifth of the loop's issue slots.
+    const int W9 = 9 * W, W3 = 3 * W;
+    auto hgroup = [&](int g) -> const float4 * { // plane 0 of group g: the candidate's if it changed, else B's
+        const int sl = gslot[g];
+        return sl >= 0 ? hm + (uint32_t)__mul24(sl, W9) : hb + (uint32_t)__mul24(g, W9);
     };
-    // slot layout inside the 5-unrolled loop is u = (g - gs) % 5: group gs -> slot 0, gs-1 -> slot 4, gs-2 -> 3, gs-3 -> 2
-    if (!skip) {
+    auto hload = [&](int g, int p) -> float4 { return hgroup(g)[(uint32_t)__mul24(p, W)]; };
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Tail ring slots are relative to gs: group gs+r keeps its xy half in slot r mod 2 and its zw half in slot r mod 3.
+    // Groups gs-3 .. gs-1 precede the first changed group (they are B's, or zero above the image).
+    float4 bufA[3], bufB[3]; // current / next input group, roles alternate per iteration
 #pragma unroll
-        for (int p = 0; p < 3; p++) {
-            if (gs < H4) ring[p][0] = hload(gs, p);
-            if (gs - 1 >= 0) ring[p][4] = hload(gs - 1, p);
-            if (gs - 2 >= 0) ring[p][3] = hload(gs - 2, p);
-            if (gs - 3 >= 0) ring[p][2] = hload(gs - 3, p);
+    for (int p = 0; p < 3; p++) {
+        float4 g1 = zero4, g2 = zero4, g3 = zero4;
+        bufA[p] = zero4; bufB[p] = zero4;
+        if (!skip) {
+            if (gs < H4) bufA[p] = hload(gs, p);
+            if (gs - 1 >= 0) g1 = hload(gs - 1, p);
+            if (gs - 2 >= 0) g2 = hload(gs - 2, p);
+            if (gs - 3 >= 0) g3 = hload(gs - 3, p);
         }
+        s_xy[1][p][t] = make_float2(g1.x, g1.y); s_zw[2][p][t] = make_float2(g1.z, g1.w); // r = -1
+        s_xy[0][p][t] = make_float2(g2.x, g2.y); s_zw[1][p][t] = make_float2(g2.z, g2.w); // r = -2
+        s_zw[0][p][t] = make_float2(g3.z, g3.w);                                          // r = -3
     }
-    // map inputs of row group g-1 travel one iteration ahead of their use
-    float4 n_i1 = make_float4(0.f, 0.f, 0.f, 0.f), n_m1 = n_i1, n_s11 = n_i1, n_x = n_i1;
-    uint4 n_pa = make_uint4(0, 0, 0, 0), n_pb = n_pa;
-    if (!skip && gs >= 1) {
-        const int gm = gs - 1;
-        n_i1 = img1[(size_t)gm * W]; n_m1 = mu1[(size_t)gm * W]; n_s11 = s11[(size_t)gm * W];
-        if (S0) { n_pa = pk[(size_t)gm * W * 2]; n_pb = pk[(size_t)gm * W * 2 + 1]; }
-        else { const short sl = gslot[gm]; n_x = sl >= 0 ? xm[(size_t)sl * 3 * W] : xb[(size_t)gm * 3 * W]; }
+    // running pointers of the map inputs of row group g-1 (valid from g = 1 on)
+    const int gm0 = gs >= 1 ? gs - 1 : 0;
+    const float4 *p_i1 = img1 + (uint32_t)__mul24(gm0, W), *p_m1 = mu1 + (uint32_t)__mul24(gm0, W), *p_s11 = s11 + (uint32_t)__mul24(gm0, W);
+    const uint4 *p_pk = S0 ? pk + 2u * (uint32_t)__mul24(gm0, W) : nullptr;
+    const uint32_t *bm = (S0 && P.perceptual && !is_base) ? P.bitmap + (size_t)k * (G.W * G.H / 32) : nullptr;
+#define SNES_VGROUP(U, CUR, NXT)                                                                                              \
+    {                                                                                                                         \
+        const int g = g0 + (U);                                                                                               \
+        if (g > H4) break;                                                                                                    \
+        if (is_base && active) { /* record g */                                                                               \
+            float *cf = ckf + (size_t)g * 18 * W;                                                                             \
+            double *ca = cka + (size_t)g * 6 * W;                                                                             \
+            _Pragma("unroll") for (int p = 0; p < 3; p++)                                                                     \
+                _Pragma("unroll") for (int q = 0; q < 3; q++) { cf[(size_t)(p * 6 + q) * W] = sa[p][q]; cf[(size_t)(p * 6 + 3 + q) * W] = sb[p][q]; } \
+            _Pragma("unroll") for (int q = 0; q < 6; q++) ca[(size_t)q * W] = acc[q];                                         \
+        }                                                                                                                     \
+        if (g + 1 < H4) { const float4 *hp = hgroup(g + 1); NXT[0] = hp[0]; NXT[1] = hp[W]; NXT[2] = hp[2 * W]; }             \
+        else { NXT[0] = zero4; NXT[1] = zero4; NXT[2] = zero4; }                                                              \
+        /* inputs of the maps of row group g-1, consumed after the recurrence steps below */                                  \
+        float4 c_i1 = zero4, c_m1 = zero4, c_s11 = zero4, c_x = zero4;                                                        \
+        uint4 c_pa = make_uint4(0, 0, 0, 0), c_pb = c_pa;                                                                     \
+        if (g >= 1) {                                                                                                         \
+            c_i1 = *p_i1; c_m1 = *p_m1; c_s11 = *p_s11;                                                                       \
+            p_i1 += W; p_m1 += W; p_s11 += W;                                                                                 \
+            if (S0) { c_pa = p_pk[0]; c_pb = p_pk[1]; p_pk += 2 * W; }                                                        \
+            else { const int sl = gslot[g - 1]; c_x = sl >= 0 ? xm[(uint32_t)__mul24(sl, W3)] : xb[(uint32_t)__mul24(g - 1, W3)]; } \
+        }                                                                                                                     \
+        float outp[3][4];                                                                                                     \
+        _Pragma("unroll") for (int p = 0; p < 3; p++) {                                                                       \
+            const float2 tz = s_zw[(U) % 3][p][t], tx = s_xy[(U) % 2][p][t]; /* group g-3 second half, g-2 first half */      \
+            s_zw[(U) % 3][p][t] = make_float2(CUR[p].z, CUR[p].w);                                                            \
+            s_xy[(U) % 2][p][t] = make_float2(CUR[p].x, CUR[p].y);                                                            \
+            SNES_VSTEP(tz.x + CUR[p].x, sa[p], sb[p], outp[p][0])                                                             \
+            SNES_VSTEP(tz.y + CUR[p].y, sb[p], sa[p], outp[p][1])                                                             \
+            SNES_VSTEP(tx.x + CUR[p].z, sa[p], sb[p], outp[p][2])                                                             \
+            SNES_VSTEP(tx.y + CUR[p].w, sb[p], sa[p], outp[p][3])                                                             \
+        }                                                                                                                     \
+        if (g >= 1) {                                                                                                         \
+            float i2v[4] = {c_x.x, c_x.y, c_x.z, c_x.w};                                                                      \
+            if (S0) {                                                                                                         \
+                uint32_t c0, c1, c2, c3;                                                                                      \
+                if (bm) { /* rows 4(g-1)..4(g-1)+3 of column x */                                                             \
+                    const int px0 = ((g - 1) << 2) * W + x;                                                                   \
+                    c0 = won_bit(bm, px0) ? (uint32_t)P.ncol : (c_pa.x >> 24); c1 = won_bit(bm, px0 + W) ? (uint32_t)P.ncol : (c_pa.z >> 24);               \
+                    c2 = won_bit(bm, px0 + 2 * W) ? (uint32_t)P.ncol : (c_pb.x >> 24); c3 = won_bit(bm, px0 + 3 * W) ? (uint32_t)P.ncol : (c_pb.z >> 24);   \
+                } else {                                                                                                      \
+                    c0 = sparse_ci(c_pa.x, c_pa.y & never, crgb, (uint32_t)P.ncol); c1 = sparse_ci(c_pa.z, c_pa.w & never, crgb, (uint32_t)P.ncol);         \
+                    c2 = sparse_ci(c_pb.x, c_pb.y & never, crgb, (uint32_t)P.ncol); c3 = sparse_ci(c_pb.z, c_pb.w & never, crgb, (uint32_t)P.ncol);         \
+                }                                                                                                             \
+                i2v[0] = c0 == (uint32_t)P.ncol ? cand_v : s_lut[c0]; i2v[1] = c1 == (uint32_t)P.ncol ? cand_v : s_lut[c1];   \
+                i2v[2] = c2 == (uint32_t)P.ncol ? cand_v : s_lut[c2]; i2v[3] = c3 == (uint32_t)P.ncol ? cand_v : s_lut[c3];   \
+            }                                                                                                                 \
+            const float i1v[4] = {c_i1.x, c_i1.y, c_i1.z, c_i1.w}, m1v[4] = {c_m1.x, c_m1.y, c_m1.z, c_m1.w}, s11v[4] = {c_s11.x, c_s11.y, c_s11.z, c_s11.w}; \
+            _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                                   \
+                const float m1 = m1v[q], m2 = outp[0][q], v11 = s11v[q], v22 = outp[1][q], v12 = outp[2][q];                  \
+                const float i1 = i1v[q], i2 = i2v[q];                                                                         \
+                const float mu11 = m1 * m1, mu22 = m2 * m2, mu12 = m1 * m2;                                                   \
+                const float mu_diff = m1 - m2;                                                                                \
+                const float num_m = fmaf(mu_diff, -mu_diff, 1.0f);                                                            \
+                const float num_s = fmaf(2.0f, v12 - mu12, 0.0009f);                                                          \
+                const float denom_s = (v11 - mu11) + (v22 - mu22) + 0.0009f;                                                  \
+                double d = 1.0 - (double)((num_m * num_s) / denom_s);                                                         \
+                d = d > 0.0 ? d : 0.0;                                                                                        \
+                acc[0] += d;                                                                                                  \
+                const double dd = d * d;                                                                                      \
+                acc[1] += dd * dd;                                                                                            \
+                const double d1 = (1.0 + (double)fabsf(i2 - m2)) / (1.0 + (double)fabsf(i1 - m1)) - 1.0;                      \
+                const double art = d1 > 0.0 ? d1 : 0.0;                                                                       \
+                const double det = (-d1) > 0.0 ? (-d1) : 0.0;                                                                 \
+                acc[2] += art;                                                                                                \
+                const double a2 = art * art;                                                                                  \
+                acc[3] += a2 * a2;                                                                                            \
+                acc[4] += det;                                                                                                \
+                const double l2 = det * det;                                                                                  \
+                acc[5] += l2 * l2;                                                                                            \
+            }                                                                                                                 \
+        }                                                                                                                     \
     }
-    for (int g0 = gs; g0 <= H4; g0 += 5) {
-#pragma unroll
-        for (int u = 0; u < 5; u++) {
-            const int g = g0 + u;
-            if (g > H4) break;
-            if (is_base && active) { // record g
-                float *cf = ckf + (size_t)g * 18 * W;
-                double *ca = cka + (size_t)g * 6 * W;
-#pragma unroll
-                for (int p = 0; p < 3; p++)
-#pragma unroll
-                    for (int q = 0; q < 3; q++) { cf[(size_t)(p * 6 + q) * W] = sa[p][q]; cf[(size_t)(p * 6 + 3 + q) * W] = sb[p][q]; }
-#pragma unroll
-                for (int q = 0; q < 6; q++) ca[(size_t)q * W] = acc[q];
-            }
-            const int un = (u + 1) % 5, ua = (u + 2) % 5, ub = (u + 3) % 5;
-            const float4 c_i1 = n_i1, c_m1 = n_m1, c_s11 = n_s11, c_x = n_x; const uint4 c_pa = n_pa, c_pb = n_pb;
-            if (g + 1 < H4) { ring[0][un] = hload(g + 1, 0); ring[1][un] = hload(g + 1, 1); ring[2][un] = hload(g + 1, 2); }
-            else { ring[0][un] = make_float4(0.f, 0.f, 0.f, 0.f); ring[1][un] = ring[0][un]; ring[2][un] = ring[0][un]; }
-            if (g < H4) {
-                n_i1 = img1[(size_t)g * W]; n_m1 = mu1[(size_t)g * W]; n_s11 = s11[(size_t)g * W];
-                if (S0) { n_pa = pk[(size_t)g * W * 2]; n_pb = pk[(size_t)g * W * 2 + 1]; }
-                else { const short sl = gslot[g]; n_x = sl >= 0 ? xm[(size_t)sl * 3 * W] : xb[(size_t)g * 3 * W]; }
-            }
-            float i2v[4] = {c_x.x, c_x.y, c_x.z, c_x.w};
-            if (S0 && g >= 1) {
-                uint32_t c0, c1, c2, c3;
-                if (P.perceptual && !is_base) { // rows 4(g-1)..4(g-1)+3 of column x
-                    const uint32_t *bm = P.bitmap + (size_t)k * (G.W * G.H / 32);
-                    const int px0 = ((g - 1) << 2) * W + x;
-                    c0 = won_bit(bm, px0) ? (uint32_t)P.ncol : (c_pa.x >> 24); c1 = won_bit(bm, px0 + W) ? (uint32_t)P.ncol : (c_pa.z >> 24);
-                    c2 = won_bit(bm, px0 + 2 * W) ? (uint32_t)P.ncol : (c_pb.x >> 24); c3 = won_bit(bm, px0 + 3 * W) ? (uint32_t)P.ncol : (c_pb.z >> 24);
-                } else {
-                    c0 = sparse_ci(c_pa.x, c_pa.y & never, crgb, (uint32_t)P.ncol); c1 = sparse_ci(c_pa.z, c_pa.w & never, crgb, (uint32_t)P.ncol);
-                    c2 = sparse_ci(c_pb.x, c_pb.y & never, crgb, (uint32_t)P.ncol); c3 = sparse_ci(c_pb.z, c_pb.w & never, crgb, (uint32_t)P.ncol);
-                }
-                i2v[0] = c0 == (uint32_t)P.ncol ? cand_v : lut[c0]; i2v[1] = c1 == (uint32_t)P.ncol ? cand_v : lut[c1];
-                i2v[2] = c2 == (uint32_t)P.ncol ? cand_v : lut[c2]; i2v[3] = c3 == (uint32_t)P.ncol ? cand_v : lut[c3];
-            }
-            const float i1v[4] = {c_i1.x, c_i1.y, c_i1.z, c_i1.w}, m1v[4] = {c_m1.x, c_m1.y, c_m1.z, c_m1.w}, s11v[4] = {c_s11.x, c_s11.y, c_s11.z, c_s11.w};
-            float in[3][4], top[3][4];
-#pragma unroll
-            for (int p = 0; p < 3; p++) {
-                in[p][0] = ring[p][u].x; in[p][1] = ring[p][u].y; in[p][2] = ring[p][u].z; in[p][3] = ring[p][u].w;
-                top[p][0] = ring[p][ua].z; top[p][1] = ring[p][ua].w; top[p][2] = ring[p][ub].x; top[p][3] = ring[p][ub].y;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                float outp[3];
-                if ((q & 1) == 0) {
-                    SNES_VSTEP(top[0][q] + in[0][q], sa[0], sb[0], outp[0]) SNES_VSTEP(top[1][q] + in[1][q], sa[1], sb[1], outp[1]) SNES_VSTEP(top[2][q] + in[2][q], sa[2], sb[2], outp[2])
-                } else {
-                    SNES_VSTEP(top[0][q] + in[0][q], sb[0], sa[0], outp[0]) SNES_VSTEP(top[1][q] + in[1][q], sb[1], sa[1], outp[1]) SNES_VSTEP(top[2][q] + in[2][q], sb[2], sa[2], outp[2])
-                }
-                if (g >= 1) {
-                    const float m1 = m1v[q], m2 = outp[0], v11 = s11v[q], v22 = outp[1], v12 = outp[2];
-                    const float i1 = i1v[q], i2 = i2v[q];
-                    const float mu11 = m1 * m1, mu22 = m2 * m2, mu12 = m1 * m2;
-                    const float mu_diff = m1 - m2;
-                    const float num_m = fmaf(mu_diff, -mu_diff, 1.0f);
-                    const float num_s = fmaf(2.0f, v12 - mu12, 0.0009f);
-                    const float denom_s = (v11 - mu11) + (v22 - mu22) + 0.0009f;
-                    double d = 1.0 - (double)((num_m * num_s) / denom_s);
-                    d = d > 0.0 ? d : 0.0;
-                    acc[0] += d;
-                    const double dd = d * d;
-                    acc[1] += dd * dd;
-                    const double d1 = (1.0 + (double)fabsf(i2 - m2)) / (1.0 + (double)fabsf(i1 - m1)) - 1.0;
-                    const double art = d1 > 0.0 ? d1 : 0.0;
-                    const double det = (-d1) > 0.0 ? (-d1) : 0.0;
-                    acc[2] += art;
-                    const double a2 = art * art;
-                    acc[3] += a2 * a2;
-                    acc[4] += det;
-                    const double l2 = det * det;
-                    acc[5] += l2 * l2;
-                }
-            }
-        }
+    for (int g0 = gs; g0 <= H4; g0 += 6) {
+        SNES_VGROUP(0, bufA, bufB) SNES_VGROUP(1, bufB, bufA) SNES_VGROUP(2, bufA, bufB)
+        SNES_VGROUP(3, bufB, bufA) SNES_VGROUP(4, bufA, bufB) SNES_VGROUP(5, bufB, bufA)
     }
+#undef SNES_VGROUP
     if (is_base && active) { // final record
         double *ca = cka + (size_t)(H4 + 1) * 6 * W;
 #pragma unroll
         for (int q = 0; q < 6; q++) ca[(size_t)q * W] = acc[q];
     }
+    __syncthreads(); // the tail ring is dead: its space becomes the reduction scratch
 #pragma unroll
     for (int q = 0; q < 6; q++) red[t][q] = active ? acc[q] : 0.0;
     __syncthreads();
