@@ -50,6 +50,7 @@ struct SparseGeom {
 
 struct SparseParams {
     Geom G; SparseGeom S; BlurK K;
+    int s_first; // k_sparse_v: first scale of the launch (blockIdx.y counts from it)
     int ncand, k0, base, ncol, is_base; // candidates of this launch occupy storage indices [k0, k0+ncand); base = index of B
     const unsigned long long *pack, *packC4, *packR4;
     const uint4 *plist; const int *plist_count; // contested pixels of the slot: {px, rgb, thr, 0}
@@ -507,7 +508,15 @@ __global__ __launch_bounds__(64) void k_sparse_h(SparseParams P) {
 // registers; the trailing filter taps — rows 4g-10..4g-7, i.e. the second half of group g-3 and the first half of
 // group g-2 — come back from a per-thread LDS ring (read, then overwritten by the same thread: no barrier), and the
 // map inputs are loaded at the top of the iteration that consumes them, behind the twelve recurrence steps.
-__global__ __launch_bounds__(256, 4) void k_sparse_v(SparseParams P) {
+// UNI: scales at least 64 wide — a wave's 64 columns belong to one (candidate, channel) pair, so the first changed
+// group, the loop counter, every border test and the group -> slot choice are wave-uniform and live in SGPRs (scalar
+// branches instead of exec-mask regions with zero-filled defaults).  A wave skips only if all its columns do; a skipped
+// column inside a working wave recomputes B's values from the same checkpoint, bit for bit.
+// S0M / BM: whether the launch is scale 0 alone (pixels from the pack, not from XYB planes) / scores the image B —
+// 0 no, 1 yes, 2 decided at run time.  The candidates' launch keeps both at 2: the register allocator lands on 13 spills
+// at 128 VGPRs there and on 30-70 with either specialised; B's launches are specialised and take 2 waves' worth of registers.
+template <bool UNI, int S0M, int BM>
+__global__ __launch_bounds__(256, BM == 1 ? 2 : 4) void k_sparse_v(SparseParams P) {
     __shared__ float s_lut[256];
     __shared__ short s_gslot[256];
     // tails: xy halves two deep, zw halves three deep, [slot][plane][thread]; the pooling reduction reuses the space
@@ -517,15 +526,15 @@ __global__ __launch_bounds__(256, 4) void k_sparse_v(SparseParams P) {
     double (*red)[6] = reinterpret_cast<double (*)[6]>(s_raw);
     static_assert(sizeof(s_raw) >= 256 * 6 * sizeof(double), "reduction scratch must fit the tail ring");
     const Geom &G = P.G;
-    const int s = blockIdx.y;
+    const int s = (int)blockIdx.y + P.s_first;
     if (s >= G.nscales) return;
     const int W = G.sw[s], H = G.sh[s];
+    const bool S0 = S0M == 2 ? s == 0 : S0M == 1;
     const int t = threadIdx.x;
     const int ppw = 256 / W;
-    const bool is_base = P.is_base != 0;
+    const bool is_base = BM == 2 ? P.is_base != 0 : BM == 1;
     const int npairs = is_base ? 3 : P.ncand * 3;
     if ((int)blockIdx.x * ppw >= npairs) return;
-    const bool S0 = (s == 0);
     const int ql = t / W, x = t - ql * W;
     const int pair_raw = blockIdx.x * ppw + ql;
     const bool active = pair_raw < npairs;
@@ -548,7 +557,12 @@ __global__ __launch_bounds__(256, 4) void k_sparse_v(SparseParams P) {
     const int ng = M->ngroups[s];
     const int cmin = (M->xmin >> s) - 5; // columns <= cmin see only unchanged inputs
     const bool skip = !is_base && (ng == 0 || x <= cmin);
-    const int gs = skip ? H4 + 1 : (is_base ? 0 : (int)M->glist[P.S.goff[s]]);
+    int gs = skip ? H4 + 1 : (is_base ? 0 : (int)M->glist[P.S.goff[s]]);
+    if (UNI) { // the smallest first-group of the wave: the pair's, unless every column skips
+        const int gs_pair = is_base ? 0 : (ng == 0 ? H4 + 1 : (int)M->glist[P.S.goff[s]]);
+        gs = __builtin_amdgcn_readfirstlane(__all(skip) ? H4 + 1 : gs_pair);
+    }
+#define SNES_GSLOT(I) (UNI ? __builtin_amdgcn_readfirstlane((int)gslot[I]) : (int)gslot[I])
     const float cand_v = is_base ? 0.0f : P.cand_tab[8 * (size_t)k + 3 + ch];
     const uint32_t crgb = is_base ? 0u : __float_as_uint(P.cand_tab[8 * (size_t)k + 6]);
     const uint32_t never = is_base ? 0u : 0xffffffffu;
@@ -593,7 +607,7 @@ __global__ __launch_bounds__(256, 4) void k_sparse_v(SparseParams P) {
     // multiplies of plain size_t indexing were a fifth of the loop's issue slots.
     const int W9 = 9 * W, W3 = 3 * W;
     auto hgroup = [&](int g) -> const float4 * { // plane 0 of group g: the candidate's if it changed, else B's
-        const int sl = gslot[g];
+        const int sl = SNES_GSLOT(g);
         return sl >= 0 ? hm + (uint32_t)__mul24(sl, W9) : hb + (uint32_t)__mul24(g, W9);
     };
     auto hload = [&](int g, int p) -> float4 { return hgroup(g)[(uint32_t)__mul24(p, W)]; };
@@ -605,7 +619,7 @@ __global__ __launch_bounds__(256, 4) void k_sparse_v(SparseParams P) {
     for (int p = 0; p < 3; p++) {
         float4 g1 = zero4, g2 = zero4, g3 = zero4;
         bufA[p] = zero4; bufB[p] = zero4;
-        if (!skip) {
+        if (UNI ? gs <= H4 : !skip) { // (a skipping wave has gs = H4+1: nothing to fetch)
             if (gs < H4) bufA[p] = hload(gs, p);
             if (gs - 1 >= 0) g1 = hload(gs - 1, p);
             if (gs - 2 >= 0) g2 = hload(gs - 2, p);
@@ -620,16 +634,26 @@ __global__ __launch_bounds__(256, 4) void k_sparse_v(SparseParams P) {
     const float4 *p_i1 = img1 + (uint32_t)__mul24(gm0, W), *p_m1 = mu1 + (uint32_t)__mul24(gm0, W), *p_s11 = s11 + (uint32_t)__mul24(gm0, W);
     const uint4 *p_pk = S0 ? pk + 2u * (uint32_t)__mul24(gm0, W) : nullptr;
     const uint32_t *bm = (S0 && P.perceptual && !is_base) ? P.bitmap + (size_t)k * (G.W * G.H / 32) : nullptr;
+    float *ck_f = BM == 1 ? ckf + (size_t)gs * 18 * W : nullptr; // B only: running pointers of the record being written
+    double *ck_a = BM == 1 ? cka + (size_t)gs * 6 * W : nullptr;
 #define SNES_VGROUP(U, CUR, NXT)                                                                                              \
     {                                                                                                                         \
         const int g = g0 + (U);                                                                                               \
         if (g > H4) break;                                                                                                    \
-        if (is_base && active) { /* record g */                                                                               \
+        if (BM == 2 && is_base && active) { /* record g (run-time flavour) */                                                 \
             float *cf = ckf + (size_t)g * 18 * W;                                                                             \
             double *ca = cka + (size_t)g * 6 * W;                                                                             \
             _Pragma("unroll") for (int p = 0; p < 3; p++)                                                                     \
                 _Pragma("unroll") for (int q = 0; q < 3; q++) { cf[(size_t)(p * 6 + q) * W] = sa[p][q]; cf[(size_t)(p * 6 + 3 + q) * W] = sb[p][q]; } \
             _Pragma("unroll") for (int q = 0; q < 6; q++) ca[(size_t)q * W] = acc[q];                                         \
+        }                                                                                                                     \
+        if (BM == 1 && active) { /* record g */                                                                               \
+            _Pragma("unroll") for (int p = 0; p < 3; p++)                                                                     \
+                _Pragma("unroll") for (int q = 0; q < 3; q++) {                                                               \
+                    ck_f[(uint32_t)__mul24(p * 6 + q, W)] = sa[p][q]; ck_f[(uint32_t)__mul24(p * 6 + 3 + q, W)] = sb[p][q];   \
+                }                                                                                                             \
+            _Pragma("unroll") for (int q = 0; q < 6; q++) ck_a[(uint32_t)__mul24(q, W)] = acc[q];                             \
+            ck_f += 18 * W; ck_a += 6 * W;                                                                                    \
         }                                                                                                                     \
         if (g + 1 < H4) { const float4 *hp = hgroup(g + 1); NXT[0] = hp[0]; NXT[1] = hp[W]; NXT[2] = hp[2 * W]; }             \
         else { NXT[0] = zero4; NXT[1] = zero4; NXT[2] = zero4; }                                                              \
@@ -640,7 +664,7 @@ __global__ __launch_bounds__(256, 4) void k_sparse_v(SparseParams P) {
             c_i1 = *p_i1; c_m1 = *p_m1; c_s11 = *p_s11;                                                                       \
             p_i1 += W; p_m1 += W; p_s11 += W;                                                                                 \
             if (S0) { c_pa = p_pk[0]; c_pb = p_pk[1]; p_pk += 2 * W; }                                                        \
-            else { const int sl = gslot[g - 1]; c_x = sl >= 0 ? xm[(uint32_t)__mul24(sl, W3)] : xb[(uint32_t)__mul24(g - 1, W3)]; } \
+            else { const int sl = SNES_GSLOT(g - 1); c_x = sl >= 0 ? xm[(uint32_t)__mul24(sl, W3)] : xb[(uint32_t)__mul24(g - 1, W3)]; } \
         }                                                                                                                     \
         float outp[3][4];                                                                                                     \
         _Pragma("unroll") for (int p = 0; p < 3; p++) {                                                                       \
@@ -656,7 +680,9 @@ __global__ __launch_bounds__(256, 4) void k_sparse_v(SparseParams P) {
             float i2v[4] = {c_x.x, c_x.y, c_x.z, c_x.w};                                                                      \
             if (S0) {                                                                                                         \
                 uint32_t c0, c1, c2, c3;                                                                                      \
-                if (bm) { /* rows 4(g-1)..4(g-1)+3 of column x */                                                             \
+                if (is_base || SNES_GSLOT(g - 1) < 0) { /* no pixel of an unchanged group is won: B's colour indices as they are */ \
+                    c0 = c_pa.x >> 24; c1 = c_pa.z >> 24; c2 = c_pb.x >> 24; c3 = c_pb.z >> 24;                               \
+                } else if (bm) { /* rows 4(g-1)..4(g-1)+3 of column x */                                                      \
                     const int px0 = ((g - 1) << 2) * W + x;                                                                   \
                     c0 = won_bit(bm, px0) ? (uint32_t)P.ncol : (c_pa.x >> 24); c1 = won_bit(bm, px0 + W) ? (uint32_t)P.ncol : (c_pa.z >> 24);               \
                     c2 = won_bit(bm, px0 + 2 * W) ? (uint32_t)P.ncol : (c_pb.x >> 24); c3 = won_bit(bm, px0 + 3 * W) ? (uint32_t)P.ncol : (c_pb.z >> 24);   \
@@ -698,6 +724,7 @@ __global__ __launch_bounds__(256, 4) void k_sparse_v(SparseParams P) {
         SNES_VGROUP(3, bufB, bufA) SNES_VGROUP(4, bufA, bufB) SNES_VGROUP(5, bufB, bufA)
     }
 #undef SNES_VGROUP
+#undef SNES_GSLOT
     if (is_base && active) { // final record
         double *ca = cka + (size_t)(H4 + 1) * 6 * W;
 #pragma unroll
