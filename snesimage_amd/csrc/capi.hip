@@ -369,19 +369,6 @@ int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double
     return SNES_OK;
 }
 
-// k_sparse_v: the wave-uniform instantiation for the scales at least 64 wide (they come first), the general one for the rest
-void launch_sparse_v(const Geom &G, SparseParams P, unsigned npairs, hipStream_t stream) {
-    P.s_first = 0;
-    if (!P.is_base) { hipLaunchKernelGGL((k_sparse_v<false, 2, 2>), dim3(npairs, (unsigned)G.nscales), dim3(256), 0, stream, P); return; }
-    int nu = 0;
-    while (nu < G.nscales && G.sw[nu] >= 64) nu++;
-    int s = 1;
-    if (nu > 0) hipLaunchKernelGGL((k_sparse_v<true, 1, 1>), dim3(npairs, 1), dim3(256), 0, stream, P);
-    else hipLaunchKernelGGL((k_sparse_v<false, 1, 1>), dim3(npairs, 1), dim3(256), 0, stream, P);
-    if (nu > s) { P.s_first = s; hipLaunchKernelGGL((k_sparse_v<true, 0, 1>), dim3(npairs, (unsigned)(nu - s)), dim3(256), 0, stream, P); s = nu; }
-    if (G.nscales > s) { P.s_first = s; hipLaunchKernelGGL((k_sparse_v<false, 0, 1>), dim3(npairs, (unsigned)(G.nscales - s)), dim3(256), 0, stream, P); }
-}
-
 // ---- row-sparse path ------------------------------------------------------------------------------------
 int32_t sparse_alloc(snesimage_ctx *c) {
     auto &sp = c->sp;
@@ -463,7 +450,7 @@ int32_t sparse_base_pass(snesimage_ctx *c) {
         hipStream_t bs = sp.side ? sp.base_stream : c->stream;
         if (sp.side) { HIPCHK(hipEventRecord(sp.ev_base_in, c->stream)); HIPCHK(hipStreamWaitEvent(bs, sp.ev_base_in, 0)); }
         hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((G.sh[0] / 4 * 3 + 15) / 16), (unsigned)G.nscales), dim3(64), 0, bs, P);
-        launch_sparse_v(G, P, 3, bs);
+        hipLaunchKernelGGL(k_sparse_v_base, dim3(3, (unsigned)G.nscales), dim3(256), 0, bs, P);
         HIPCHK(hipGetLastError());
         if (sp.side) HIPCHK(hipEventRecord(sp.ev_base_done, bs));
         sp.plist_valid = true;
@@ -491,7 +478,7 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
       hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)gx, (unsigned)G.nscales), dim3(64), 0, stream, P); }
     if (sp.side || stream != c->stream) HIPCHK(hipStreamWaitEvent(stream, sp.side ? sp.ev_base_done : c->ev_ready, 0)); // checkpoints and H output of B
     if (c->timing) { HIPCHK(hipEventRecord(tr.ev[2], stream)); HIPCHK(hipEventRecord(tr.ev[3], stream)); }
-    launch_sparse_v(G, P, nc * 3, stream);
+    hipLaunchKernelGGL(k_sparse_v, dim3(nc * 3, (unsigned)G.nscales), dim3(256), 0, stream, P);
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[4], stream));
     hipLaunchKernelGGL(k_final_score, dim3((nc + 63) / 64), dim3(64), 0, stream, sp.part + (size_t)P.k0 * G.nscales * 18, (int)nc, G, d_errors, err_stride, err_offset);
     HIPCHK(hipGetLastError());

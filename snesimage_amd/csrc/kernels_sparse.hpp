@@ -50,7 +50,6 @@ struct SparseGeom {
 
 struct SparseParams {
     Geom G; SparseGeom S; BlurK K;
-    int s_first; // k_sparse_v: first scale of the launch (blockIdx.y counts from it)
     int ncand, k0, base, ncol, is_base; // candidates of this launch occupy storage indices [k0, k0+ncand); base = index of B
     const unsigned long long *pack, *packC4, *packR4;
     const uint4 *plist; const int *plist_count; // contested pixels of the slot: {px, rgb, thr, 0}
@@ -516,7 +515,7 @@ __global__ __launch_bounds__(64) void k_sparse_h(SparseParams P) {
 // 0 no, 1 yes, 2 decided at run time.  The candidates' launch keeps both at 2: the register allocator lands on 13 spills
 // at 128 VGPRs there and on 30-70 with either specialised; B's launches are specialised and take 2 waves' worth of registers.
 template <bool UNI, int S0M, int BM>
-__global__ __launch_bounds__(256, BM == 1 ? 2 : 4) void k_sparse_v(SparseParams P) {
+__device__ __forceinline__ void sparse_v_body(const SparseParams &P, const int s) {
     __shared__ float s_lut[256];
     __shared__ short s_gslot[256];
     // tails: xy halves two deep, zw halves three deep, [slot][plane][thread]; the pooling reduction reuses the space
@@ -526,7 +525,6 @@ __global__ __launch_bounds__(256, BM == 1 ? 2 : 4) void k_sparse_v(SparseParams 
     double (*red)[6] = reinterpret_cast<double (*)[6]>(s_raw);
     static_assert(sizeof(s_raw) >= 256 * 6 * sizeof(double), "reduction scratch must fit the tail ring");
     const Geom &G = P.G;
-    const int s = (int)blockIdx.y + P.s_first;
     if (s >= G.nscales) return;
     const int W = G.sw[s], H = G.sh[s];
     const bool S0 = S0M == 2 ? s == 0 : S0M == 1;
@@ -634,6 +632,8 @@ __global__ __launch_bounds__(256, BM == 1 ? 2 : 4) void k_sparse_v(SparseParams 
     const float4 *p_i1 = img1 + (uint32_t)__mul24(gm0, W), *p_m1 = mu1 + (uint32_t)__mul24(gm0, W), *p_s11 = s11 + (uint32_t)__mul24(gm0, W);
     const uint4 *p_pk = S0 ? pk + 2u * (uint32_t)__mul24(gm0, W) : nullptr;
     const uint32_t *bm = (S0 && P.perceptual && !is_base) ? P.bitmap + (size_t)k * (G.W * G.H / 32) : nullptr;
+    float4 n_i1 = zero4, n_m1 = zero4, n_s11 = zero4, n_x = zero4; // BM == 1 only
+    uint4 n_pa = make_uint4(0, 0, 0, 0), n_pb = n_pa;
     float *ck_f = BM == 1 ? ckf + (size_t)gs * 18 * W : nullptr; // B only: running pointers of the record being written
     double *ck_a = BM == 1 ? cka + (size_t)gs * 6 * W : nullptr;
 #define SNES_VGROUP(U, CUR, NXT)                                                                                              \
@@ -660,7 +660,15 @@ __global__ __launch_bounds__(256, BM == 1 ? 2 : 4) void k_sparse_v(SparseParams 
         /* inputs of the maps of row group g-1, consumed after the recurrence steps below */                                  \
         float4 c_i1 = zero4, c_m1 = zero4, c_s11 = zero4, c_x = zero4;                                                        \
         uint4 c_pa = make_uint4(0, 0, 0, 0), c_pb = c_pa;                                                                     \
-        if (g >= 1) {                                                                                                         \
+        if (BM == 1) { /* B (single image, registers to spare): fetched one iteration ahead, group g now for iteration g+1 */  \
+            c_i1 = n_i1; c_m1 = n_m1; c_s11 = n_s11; c_x = n_x; c_pa = n_pa; c_pb = n_pb;                                      \
+            if (g < H4) {                                                                                                     \
+                n_i1 = *p_i1; n_m1 = *p_m1; n_s11 = *p_s11;                                                                   \
+                p_i1 += W; p_m1 += W; p_s11 += W;                                                                             \
+                if (S0) { n_pa = p_pk[0]; n_pb = p_pk[1]; p_pk += 2 * W; }                                                    \
+                else n_x = xb[(uint32_t)__mul24(g, W3)];                                                                      \
+            }                                                                                                                 \
+        } else if (g >= 1) {                                                                                                  \
             c_i1 = *p_i1; c_m1 = *p_m1; c_s11 = *p_s11;                                                                       \
             p_i1 += W; p_m1 += W; p_s11 += W;                                                                                 \
             if (S0) { c_pa = p_pk[0]; c_pb = p_pk[1]; p_pk += 2 * W; }                                                        \
@@ -746,6 +754,16 @@ __global__ __launch_bounds__(256, BM == 1 ? 2 : 4) void k_sparse_v(SparseParams 
 #pragma unroll
         for (int q = 0; q < 6; q++) o[q] = red[t][q];
     }
+}
+// candidates: every scale in one launch, flags decided at run time (see sparse_v_body)
+__global__ __launch_bounds__(256, 4) void k_sparse_v(SparseParams P) { sparse_v_body<false, 2, 2>(P, (int)blockIdx.y); }
+// B: one launch as well, each scale in its specialised flavour
+__global__ __launch_bounds__(256, 2) void k_sparse_v_base(SparseParams P) {
+    const int s = (int)blockIdx.y;
+    if (s >= P.G.nscales) return;
+    if (s == 0) { if (P.G.sw[0] >= 64) sparse_v_body<true, 1, 1>(P, 0); else sparse_v_body<false, 1, 1>(P, 0); }
+    else if (P.G.sw[s] >= 64) sparse_v_body<true, 0, 1>(P, s);
+    else sparse_v_body<false, 0, 1>(P, s);
 }
 #undef SNES_HSTEP
 #undef SNES_VSTEP
