@@ -117,6 +117,7 @@ struct snesimage_ctx {
     // dither path: every lane keeps the map of the best candidate it has scored in the current list, so that the commit
     // takes the winner's map instead of dithering the image again (lib.rs:237 re-runs optimize() on the winner's palette)
     uint8_t *d_bestmap = nullptr, *d_bestmaps_all = nullptr; BestRec *d_bestrec = nullptr, *d_bestrecs_all = nullptr; int *d_skip = nullptr;
+    bool map_pending = false; // without dither the optimize() that ends a step (lib.rs:237) is deferred until something reads palette_map
     bool best_valid = false, map_synced = false; // records belong to the list being committed; d_map is optimize() of the current palette
     // Additional launch lanes: chunk i of a candidate list runs on lane i % nlanes (lane 0 = the context's stream and the
     // workspace above), so the HBM-bound H pass of one chunk overlaps the VALU-bound V pass of another.
@@ -124,6 +125,7 @@ struct snesimage_ctx {
     std::vector<Lane> extra; uint32_t nlanes = 2; hipEvent_t ev_ready = nullptr;
     // Row-sparse scoring (kernels_sparse.hpp): one storage array for every lane's candidates plus the base image B
     struct Sparse {
+        bool counters_cleared = false; // k_prep cleared B's counters for the current pack
         bool enabled = false, side = true; uint32_t min_n = 128; uint32_t cap = 0; // cap = candidates per lane the arrays were sized for
         SparseGeom S{};
         float *store = nullptr, *cand_tab = nullptr, *cand_lab = nullptr, *ckf = nullptr; uint32_t *bitmap = nullptr; double *cka = nullptr, *part = nullptr;
@@ -261,6 +263,10 @@ int32_t run_prep(snesimage_ctx *c, int mode, int sp, int si) {
     P.orig = c->d_orig; P.tile_pal = c->d_tile_pal; P.pal_rgb8 = c->d_pal_rgb8; P.map = c->d_map; P.pack = c->d_pack; P.packT = c->d_packT; P.packC4 = c->d_packC4; P.packR4 = c->d_packR4; P.subC4 = c->d_subC4; P.subR4 = c->d_subR4;
     P.labpx = c->d_labpx; P.pal_lab = c->d_pal_lab;
     P.W = (int)c->W; P.H = (int)c->H; P.sub_size = (int)c->sub_size; P.ncol = c->ncol; P.mode = mode; P.sp = sp; P.si = si; P.perceptual = c->perceptual ? 1 : 0;
+    c->sp.counters_cleared = false;
+    if (mode == 2 && c->sp.plist_count) { // B's item counters (lane index nlanes) and the contested-pixel count sit side by side
+        P.zero = c->sp.item_count + (size_t)c->nlanes * kMaxScales; P.nzero = kMaxScales + 1; c->sp.counters_cleared = true;
+    }
     hipLaunchKernelGGL(k_prep, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, P);
     HIPCHK(hipGetLastError());
     c->pack_valid = true; c->pack_mode = mode; c->pack_sp = sp; c->pack_si = si;
@@ -374,7 +380,7 @@ int32_t sparse_alloc(snesimage_ctx *c) {
     auto &sp = c->sp;
     if (sp.cap >= c->chunk) return SNES_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
-    dfree(sp.store); dfree(sp.cand_tab); dfree(sp.ckf); dfree(sp.cka); dfree(sp.part); dfree(sp.meta); dfree(sp.items); dfree(sp.item_count); dfree(sp.plist); dfree(sp.plist_count);
+    dfree(sp.store); dfree(sp.cand_tab); dfree(sp.ckf); dfree(sp.cka); dfree(sp.part); dfree(sp.meta); dfree(sp.items); dfree(sp.item_count); dfree(sp.plist); sp.plist_count = nullptr;
     const Geom &G = c->G;
     SparseGeom &S = sp.S;
     long long off = 0, okf = 0, oka = 0; int go = 0;
@@ -410,9 +416,11 @@ int32_t sparse_alloc(snesimage_ctx *c) {
         HIPCHK(hipEventCreateWithFlags(&sp.ev_base_in, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sp.ev_base_done, hipEventDisableTiming));
     }
-    HIPCHK(hipMalloc(&sp.item_count, sizeof(int) * kMaxScales * (c->nlanes + 1)));
+    HIPCHK(hipMalloc(&sp.item_count, sizeof(int) * (kMaxScales * (c->nlanes + 1) + 1))); // + the contested-pixel count, right behind B's counters
+    HIPCHK(hipMemsetAsync(sp.item_count, 0, sizeof(int) * (kMaxScales * (c->nlanes + 1) + 1), c->stream)); // every launch group leaves its counters cleared
+    sp.plist_count = sp.item_count + (size_t)kMaxScales * (c->nlanes + 1);
+    sp.counters_cleared = true;
     HIPCHK(hipMalloc(&sp.plist, sizeof(uint4) * c->npx));
-    HIPCHK(hipMalloc(&sp.plist_count, sizeof(int)));
     sp.cap = c->chunk; sp.plist_valid = false;
     return SNES_OK;
 }
@@ -436,11 +444,11 @@ int32_t sparse_base_pass(snesimage_ctx *c) {
     auto &sp = c->sp;
     const Geom &G = c->G;
     if (!sp.plist_valid) {
-        HIPCHK(hipMemsetAsync(sp.plist_count, 0, sizeof(int), c->stream));
+        if (!sp.counters_cleared) HIPCHK(hipMemsetAsync(sp.item_count + (size_t)c->nlanes * kMaxScales, 0, sizeof(int) * (kMaxScales + 1), c->stream)); // normally k_prep did it
+        sp.counters_cleared = false; // about to be used
         hipLaunchKernelGGL(k_build_plist, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, c->d_pack, (int)c->npx, sp.plist, sp.plist_count);
         SparseParams P = sparse_params(c, c->nlanes); // B has its own item list and counters
         P.is_base = 1; P.ncand = 1; P.k0 = P.base;
-        HIPCHK(hipMemsetAsync(P.item_count, 0, sizeof(int) * kMaxScales, c->stream));
         hipLaunchKernelGGL(k_sparse_scan, dim3(1), dim3(1024), 0, c->stream, P);
         hipLaunchKernelGGL(k_base_down, dim3((unsigned)((G.W / 32) * (G.H / 32))), dim3(256), 0, c->stream, P); // B: every row of every scale
         // B's H and V passes are long single-image sweeps (latency-bound); they run on their own stream beside the
@@ -466,7 +474,6 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     snesimage_ctx::TimingRec tr{}; tr.n = nc;
     if (c->timing) { for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&tr.ev[i])); HIPCHK(hipEventRecord(tr.ev[0], stream)); }
     hipLaunchKernelGGL(k_candidate_tables, dim3((nc + 63) / 64), dim3(64), 0, stream, d_rgb5, (int)nc, c->d_eotf, sp.cand_tab + 8 * (size_t)P.k0);
-    HIPCHK(hipMemsetAsync(P.item_count, 0, sizeof(int) * kMaxScales, stream));
     if (c->perceptual) {
         hipLaunchKernelGGL(k_candidate_lab, dim3((nc + 63) / 64), dim3(64), 0, stream, sp.cand_tab + 8 * (size_t)P.k0, (int)nc, c->d_lab_eotf, sp.cand_lab + 3 * (size_t)P.k0);
         HIPCHK(hipMemsetAsync(sp.bitmap + (size_t)P.k0 * (c->npx / 32), 0, sizeof(uint32_t) * (c->npx / 32) * nc, stream));
@@ -480,7 +487,7 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     if (c->timing) { HIPCHK(hipEventRecord(tr.ev[2], stream)); HIPCHK(hipEventRecord(tr.ev[3], stream)); }
     hipLaunchKernelGGL(k_sparse_v, dim3(nc * 3, (unsigned)G.nscales), dim3(256), 0, stream, P);
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[4], stream));
-    hipLaunchKernelGGL(k_final_score, dim3((nc + 63) / 64), dim3(64), 0, stream, sp.part + (size_t)P.k0 * G.nscales * 18, (int)nc, G, d_errors, err_stride, err_offset);
+    hipLaunchKernelGGL(k_final_score, dim3((nc + 63) / 64), dim3(64), 0, stream, sp.part + (size_t)P.k0 * G.nscales * 18, (int)nc, G, d_errors, err_stride, err_offset, P.item_count, (int)kMaxScales);
     HIPCHK(hipGetLastError());
     if (c->timing) { HIPCHK(hipEventRecord(tr.ev[5], stream)); c->t_pending.push_back(tr); }
     return SNES_OK;
@@ -527,6 +534,8 @@ int32_t score_list(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t n, double *
     return SNES_OK;
 }
 
+int32_t ensure_map(snesimage_ctx *c);
+
 // optimize() on the current palette: no-dither -> argmin per pixel; dither -> serial error diffusion kernel
 int32_t do_optimize(snesimage_ctx *c, bool may_skip = false) {
     CHECK(ensure_tables(c));
@@ -547,12 +556,13 @@ int32_t do_optimize(snesimage_ctx *c, bool may_skip = false) {
         HIPCHK(hipGetLastError());
         c->pack_valid = false;
     }
-    c->inc_valid = false; c->map_synced = true;
+    c->inc_valid = false; c->map_synced = true; c->map_pending = false;
     return SNES_OK;
 }
 
 // error() of the stored palette_map -> d_out (device)
 int32_t do_error(snesimage_ctx *c, double *d_out) {
+    CHECK(ensure_map(c));
     CHECK(alloc_workspace(c, c->chunk));
     CHECK(ensure_tables(c));
     CHECK(ensure_source(c));
@@ -595,29 +605,52 @@ int32_t drain_timing(snesimage_ctx *c) {
     return SNES_OK;
 }
 
-int32_t gen_candidates(snesimage_ctx *c, uint32_t method, uint32_t palette, uint32_t index, uint32_t channel, uint64_t seed, uint64_t step_id, uint32_t n) {
+int32_t gen_candidates(snesimage_ctx *c, uint32_t method, uint32_t palette, uint32_t index, uint32_t channel, uint64_t seed, uint64_t step_id, uint32_t n, uint32_t shard_rank = 0,
+                       uint32_t shard_count = 1, double *d_errors = nullptr) {
     const uint64_t key = mix64(seed ^ (step_id * 0x9E3779B97F4A7C15ull) ^ 0xD1B54A32D192ED03ull);
-    hipLaunchKernelGGL(k_gen_candidates, dim3((n + 63) / 64), dim3(64), 0, c->stream, (int)method, (int)n, key, c->d_colors, (int)(palette * c->sub_size + index), (int)channel, c->d_cand);
+    hipLaunchKernelGGL(k_gen_candidates, dim3((n + 63) / 64), dim3(64), 0, c->stream, (int)method, (int)n, key, c->d_colors, (int)(palette * c->sub_size + index), (int)channel, c->d_cand,
+                       (int)shard_rank, (int)shard_count, d_errors ? c->d_cand_sel : (uint8_t *)nullptr, d_errors);
     HIPCHK(hipGetLastError());
     return SNES_OK;
 }
 
 uint32_t method_count(uint32_t method, uint32_t n_random) { return method == SNES_METHOD_RANDOM ? (n_random ? n_random : 64u) : (method == SNES_METHOD_CHANNEL ? 32u : kNesColorCount); }
 
+// optimize() owed by the last commit (see commit): run it before anything reads or replaces what it depends on
+int32_t ensure_map(snesimage_ctx *c) {
+    if (!c->map_pending) return SNES_OK;
+    c->map_pending = false;
+    const bool inc = c->inc_valid;
+    CHECK(do_optimize(c));
+    c->inc_valid = inc; // the incumbent error was taken from the winning candidate: it is the error of exactly this map
+    return SNES_OK;
+}
+
 int32_t commit(snesimage_ctx *c, const double *d_errors, uint32_t n, uint32_t method, uint32_t palette, uint32_t index) {
+    CHECK(ensure_map(c)); // a step begun before the previous one's map was needed
+    PaletteTables T{};
+    if (c->tables_valid) { // keep the tables current: one entry changes
+        T.eotf = c->d_eotf; T.lab_eotf = c->d_lab_eotf; T.rgb8 = c->d_pal_rgb8; T.lin = c->d_pal_lin; T.xyb = c->d_pal_xyb; T.lab = c->perceptual ? c->d_pal_lab : nullptr;
+    }
     hipLaunchKernelGGL(k_commit, dim3(1), dim3(256), 0, c->stream, d_errors, (int)n, c->d_cand, c->d_colors, (int)(palette * c->sub_size + index), method == SNES_METHOD_NES ? 1 : 0, c->d_inc_err,
-                       c->d_last);
+                       c->d_last, T);
     HIPCHK(hipGetLastError());
-    c->tables_valid = false;
     c->pack_valid = false;
+    const bool was_synced = c->map_synced;
+    if (!c->dither) {
+        // lib.rs:237 / 281 / 325 (and :906) re-run optimize() on the committed palette.  Nothing in the optimizer loop reads
+        // that map (the next call builds its own pack), so it is computed when palette_map is read, not once per call.
+        c->map_pending = true; c->map_synced = true;
+        c->inc_valid = was_synced;
+        return SNES_OK;
+    }
     bool may_skip = false;
-    if (c->dither && c->d_skip) { // the winner's map is optimize() of the committed palette when a lane of this device scored it
+    if (c->d_skip) { // the winner's map is optimize() of the committed palette when a lane of this device scored it
         hipLaunchKernelGGL(k_take_best_map, dim3(1), dim3(1024), 0, c->stream, c->d_last, c->d_bestrecs_all, c->best_valid ? (int)c->nlanes : 0, c->d_bestmaps_all, (int)c->npx,
                            c->map_synced ? 1 : 0, c->d_map, c->d_skip);
         may_skip = true;
     }
     c->best_valid = false;
-    const bool was_synced = c->map_synced;
     CHECK(do_optimize(c, may_skip)); // lib.rs:237 / 281 / 325 (and :906)
     // k_commit left the committed state's error in d_inc_err (lib.rs:910 recomputes the same value) — unless the step started
     // from a map that did not belong to its palette and kept the palette: then optimize() has just replaced that map
@@ -742,7 +775,7 @@ void snesimage_destroy(snesimage_ctx *c) {
     dfree(c->d_cand); dfree(c->d_cand_sel); dfree(c->d_errs); dfree(c->d_errs_sel); dfree(c->d_inc_err); dfree(c->d_last); dfree(c->d_scratch_err); dfree(c->d_dummy_cand);
     for (auto &L : c->extra) { if (L.stream) (void)hipStreamSynchronize(L.stream); dfree(L.d_mapsC4); dfree(L.d_mapsR4); dfree(L.d_work); dfree(L.d_cand_tab); dfree(L.d_cand_lab); dfree(L.d_part); dfree(L.d_maps); dfree(L.d_mapsT); if (L.done) (void)hipEventDestroy(L.done); if (L.stream) (void)hipStreamDestroy(L.stream); }
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
-    { auto &q = c->sp; if (q.base_stream) { (void)hipStreamSynchronize(q.base_stream); (void)hipStreamDestroy(q.base_stream); (void)hipEventDestroy(q.ev_base_in); (void)hipEventDestroy(q.ev_base_done); } dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.plist_count); dfree(q.cand_lab); dfree(q.bitmap); }
+    { auto &q = c->sp; if (q.base_stream) { (void)hipStreamSynchronize(q.base_stream); (void)hipStreamDestroy(q.base_stream); (void)hipEventDestroy(q.ev_base_in); (void)hipEventDestroy(q.ev_base_done); } dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.cand_lab); dfree(q.bitmap); }
     kmeans_free(c->km);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -885,10 +918,8 @@ int32_t snesimage_step_begin(snesimage_ctx *c, uint32_t method, uint32_t palette
     const uint32_t n = method_count(method, n_total);
     CHECK(ensure_cand_capacity(c, n));
     if (method != SNES_METHOD_NES) CHECK(ensure_incumbent(c));
-    CHECK(gen_candidates(c, method, palette, index, channel, seed, step_id, n));
+    CHECK(gen_candidates(c, method, palette, index, channel, seed, step_id, n, shard_rank, shard_count, d_errors)); // + this shard's list, errors preset to +inf
     const uint32_t n_own = (n > shard_rank) ? (n - shard_rank + shard_count - 1) / shard_count : 0;
-    hipLaunchKernelGGL(k_shard_select, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->d_cand, (int)n, (int)shard_rank, (int)shard_count, c->d_cand_sel, d_errors);
-    HIPCHK(hipGetLastError());
     if (n_own) {
         CHECK(prep_for_slot(c, (int)palette, (int)index));
         // candidate j of the shard is global candidate shard_rank + j*shard_count
@@ -918,6 +949,7 @@ int32_t snesimage_set_tile_palettes(snesimage_ctx *c, const uint8_t *in) {
     if (!c || !in) return fail(SNES_ERR_ARG, "null pointer");
     for (int i = 0; i < 1024; i++) if (in[i] >= c->sub_count) return fail(SNES_ERR_ARG, "tile palette index out of range");
     CHECK(set_device(c));
+    CHECK(ensure_map(c)); // the owed optimize() belongs to the state before this change
     HIPCHK(hipMemcpyAsync(c->d_tile_pal, in, 1024, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->pack_valid = false; c->inc_valid = false; c->map_synced = false;
@@ -933,6 +965,7 @@ int32_t snesimage_get_palette_rgb5(snesimage_ctx *c, uint8_t *out) {
 int32_t snesimage_set_palette_rgb5(snesimage_ctx *c, const uint8_t *in) {
     if (!c || !in) return fail(SNES_ERR_ARG, "null pointer");
     CHECK(set_device(c));
+    CHECK(ensure_map(c));
     HIPCHK(hipMemcpyAsync(c->d_colors, in, 3 * (size_t)c->ncol, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->tables_valid = false; c->pack_valid = false; c->inc_valid = false; c->map_synced = false;
@@ -948,6 +981,7 @@ int32_t snesimage_get_palette_u16(snesimage_ctx *c, uint16_t *out) {
 int32_t snesimage_get_palette_map(snesimage_ctx *c, uint8_t *out) {
     if (!c || !out) return fail(SNES_ERR_ARG, "null pointer");
     CHECK(set_device(c));
+    CHECK(ensure_map(c));
     HIPCHK(hipMemcpyAsync(out, c->d_map, c->npx, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return SNES_OK;
@@ -956,6 +990,7 @@ int32_t snesimage_set_palette_map(snesimage_ctx *c, const uint8_t *in) {
     if (!c || !in) return fail(SNES_ERR_ARG, "null pointer");
     for (size_t i = 0; i < c->npx; i++) if (in[i] >= c->sub_size) return fail(SNES_ERR_ARG, "palette_map entry out of range");
     CHECK(set_device(c));
+    c->map_pending = false; // replaced wholesale
     HIPCHK(hipMemcpyAsync(c->d_map, in, c->npx, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->pack_valid = false; c->inc_valid = false; c->map_synced = false;

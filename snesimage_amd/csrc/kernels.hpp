@@ -108,9 +108,11 @@ struct PrepParams {
     uint8_t *subC4, *subR4; // per pixel: subpalette base (sub * sub_size) of its tile, 255 if transparent (dither path)
     const float *labpx; const float *pal_lab; // perceptual only
     int W, H, sub_size, ncol, mode, sp, si, perceptual;
+    int *zero; int nzero; // counters of the group-sparse path that belong to this pack: cleared here instead of by memset launches
 };
 
 __global__ __launch_bounds__(256) void k_prep(PrepParams P) {
+    if (P.zero && blockIdx.x == 0 && (int)threadIdx.x < P.nzero) P.zero[threadIdx.x] = 0;
     __shared__ uint32_t s_rgb8[256];
     __shared__ float s_lab[256 * 3];
     for (int i = threadIdx.x; i < P.ncol; i += blockDim.x) {
@@ -681,8 +683,9 @@ __global__ __launch_bounds__(256) void k_vpass(VParams P) {
 }
 
 // Msssim::score + `100 - score` (lib.rs:547).  One thread per candidate.
-__global__ void k_final_score(const double *__restrict__ part, int ncand, Geom G, double *__restrict__ errors, int err_stride, int err_offset) {
+__global__ void k_final_score(const double *__restrict__ part, int ncand, Geom G, double *__restrict__ errors, int err_stride, int err_offset, int *__restrict__ zero = nullptr, int nzero = 0) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (zero && c < nzero) zero[c] = 0; // the launch group's work-item counters, ready for the lane's next chunk
     if (c >= ncand) return;
     double ssim = 0.0;
     int i = 0;

@@ -279,7 +279,10 @@ __device__ __forceinline__ unsigned long long dev_mix64(unsigned long long z) {
 }
 // method 0: r,g,b sampled in that order from the counter RNG (lib.rs:206-208); 1: 32 values of one
 // channel of the current colour (lib.rs:296-297); 2: the NES table (lib.rs:252-253)
-__global__ void k_gen_candidates(int method, int n, unsigned long long key, const uint8_t *__restrict__ colors, int slot, int channel, uint8_t *__restrict__ cand) {
+// With `sel`: also the shard's own list (candidate k belongs to rank k % count, position k / count) and the error vector
+// preset to +inf — what k_shard_select does for an explicit list.
+__global__ void k_gen_candidates(int method, int n, unsigned long long key, const uint8_t *__restrict__ colors, int slot, int channel, uint8_t *__restrict__ cand,
+                                 int rank = 0, int count = 1, uint8_t *__restrict__ sel = nullptr, double *__restrict__ errors = nullptr) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     uint8_t c[3];
@@ -293,6 +296,10 @@ __global__ void k_gen_candidates(int method, int n, unsigned long long key, cons
         if (k < (int)kNesColorCount) { c[0] = kNesTableDev[k][0]; c[1] = kNesTableDev[k][1]; c[2] = kNesTableDev[k][2]; } else { c[0] = c[1] = c[2] = 0; }
     }
     cand[3 * k] = c[0]; cand[3 * k + 1] = c[1]; cand[3 * k + 2] = c[2];
+    if (sel) {
+        errors[k] = __longlong_as_double(0x7ff0000000000000ll);
+        if (k % count == rank) { const int j = k / count; sel[3 * j] = c[0]; sel[3 * j + 1] = c[1]; sel[3 * j + 2] = c[2]; }
+    }
 }
 
 // Keep candidates k with k % count == rank (compacted, in order); errors[] <- +inf everywhere.
@@ -305,8 +312,9 @@ __global__ void k_shard_select(const uint8_t *__restrict__ cand, int n, int rank
 
 // Acceptance rule: ascending k, strict `<` against the running best starting from the incumbent
 // (lib.rs:216-219, 302-305) or from f64::MAX for the NES method (lib.rs:250, 258-261).
+struct PaletteTables { const float *eotf, *lab_eotf; uint32_t *rgb8; float *lin, *xyb, *lab; }; // lab == nullptr without --perceptual-palettes
 __global__ __launch_bounds__(256) void k_commit(const double *__restrict__ errors, int n, const uint8_t *__restrict__ cand, uint8_t *__restrict__ colors, int slot, int nes, double *__restrict__ inc_err,
-                                               StepResult *__restrict__ last) {
+                                               StepResult *__restrict__ last, PaletteTables T) {
     // The sequential scan "for k ascending: if e_k < best" ends on the FIRST index attaining the minimum, provided that
     // minimum is < the starting value; a parallel (error, index) lexicographic minimum gives the same answer.
     __shared__ double s_e[256];
@@ -335,6 +343,19 @@ __global__ __launch_bounds__(256) void k_commit(const double *__restrict__ error
         changed = (nc[0] != c[0] || nc[1] != c[1] || nc[2] != c[2]) ? 1 : 0;
         c[0] = nc[0]; c[1] = nc[1]; c[2] = nc[2];
         colors[3 * slot] = c[0]; colors[3 * slot + 1] = c[1]; colors[3 * slot + 2] = c[2];
+        if (T.rgb8) { // the one changed row of the palette tables (k_palette_tables / k_palette_lab for entry `slot`)
+            const uint32_t rgb8 = rgb5_to_rgb8(c[0], c[1], c[2]);
+            const float r = T.eotf[rgb8 & 0xff], g = T.eotf[(rgb8 >> 8) & 0xff], b = T.eotf[(rgb8 >> 16) & 0xff];
+            float X, Y, B;
+            linear_to_positive_xyb(r, g, b, X, Y, B);
+            T.rgb8[slot] = rgb8;
+            T.lin[3 * slot] = r; T.lin[3 * slot + 1] = g; T.lin[3 * slot + 2] = b;
+            T.xyb[3 * slot] = X; T.xyb[3 * slot + 1] = Y; T.xyb[3 * slot + 2] = B;
+            if (T.lab) {
+                const Lab l = linear_to_lab(T.lab_eotf[rgb8 & 0xff], T.lab_eotf[(rgb8 >> 8) & 0xff], T.lab_eotf[(rgb8 >> 16) & 0xff]);
+                T.lab[3 * slot] = l.l; T.lab[3 * slot + 1] = l.a; T.lab[3 * slot + 2] = l.b;
+            }
+        }
         if (best < 1.7976931348623157e308) *inc_err = best; // error() of the committed state (lib.rs:910)
     }
     last->error = *inc_err; last->best_k = best_k; last->rgb5[0] = c[0]; last->rgb5[1] = c[1]; last->rgb5[2] = c[2]; last->changed = changed;

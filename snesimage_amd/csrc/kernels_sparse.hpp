@@ -758,7 +758,7 @@ __device__ __forceinline__ void sparse_v_body(const SparseParams &P, const int s
 // candidates: every scale in one launch, flags decided at run time (see sparse_v_body)
 __global__ __launch_bounds__(256, 4) void k_sparse_v(SparseParams P) { sparse_v_body<false, 2, 2>(P, (int)blockIdx.y); }
 // B: one launch as well, each scale in its specialised flavour
-__global__ __launch_bounds__(256, 2) void k_sparse_v_base(SparseParams P) {
+__global__ __launch_bounds__(256, 1) void k_sparse_v_base(SparseParams P) {
     const int s = (int)blockIdx.y;
     if (s >= P.G.nscales) return;
     if (s == 0) { if (P.G.sw[0] >= 64) sparse_v_body<true, 1, 1>(P, 0); else sparse_v_body<false, 1, 1>(P, 0); }
