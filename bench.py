@@ -250,7 +250,8 @@ def main():
         total = n_total * args.steps
         value = total / dt
         # dominant kernel of the launch group
-        sparse = args.config == "rgb" and os.environ.get("SNES_SPARSE", "1") != "0" and n_total // world >= 128
+        sparse = (args.config in ("rgb", "perceptual") and os.environ.get("SNES_SPARSE", "1") != "0"
+                  and n_total // world >= int(os.environ.get("SNES_SPARSE_MIN", "64")))
         vname, hname = ("k_sparse_v", "k_sparse_h") if sparse else ("k_vpass_fast<scale0>", "k_hpass_fast<scale0>")
         dom = vname if tim["vpass0_ms"] >= tim["hpass0_ms"] else hname
         dom_ms = max(tim["vpass0_ms"], tim["hpass0_ms"]) / max(1, tim["launches"])

@@ -126,7 +126,7 @@ struct snesimage_ctx {
     // Row-sparse scoring (kernels_sparse.hpp): one storage array for every lane's candidates plus the base image B
     struct Sparse {
         bool counters_cleared = false; // k_prep cleared B's counters for the current pack
-        bool enabled = false, side = true; uint32_t min_n = 128; uint32_t cap = 0; // cap = candidates per lane the arrays were sized for
+        bool enabled = false, side = true; uint32_t min_n = 64; uint32_t cap = 0; // cap = candidates per lane the arrays were sized for
         SparseGeom S{};
         float *store = nullptr, *cand_tab = nullptr, *cand_lab = nullptr, *ckf = nullptr; uint32_t *bitmap = nullptr; double *cka = nullptr, *part = nullptr;
         CandMeta *meta = nullptr; unsigned int *items = nullptr; int *item_count = nullptr; long long item_stride = 0;
@@ -627,7 +627,7 @@ int32_t ensure_map(snesimage_ctx *c) {
 }
 
 int32_t commit(snesimage_ctx *c, const double *d_errors, uint32_t n, uint32_t method, uint32_t palette, uint32_t index) {
-    CHECK(ensure_map(c)); // a step begun before the previous one's map was needed
+    // (an optimize() still owed by the previous commit is simply superseded: nobody looked at that map)
     PaletteTables T{};
     if (c->tables_valid) { // keep the tables current: one entry changes
         T.eotf = c->d_eotf; T.lab_eotf = c->d_lab_eotf; T.rgb8 = c->d_pal_rgb8; T.lin = c->d_pal_lin; T.xyb = c->d_pal_xyb; T.lab = c->perceptual ? c->d_pal_lab : nullptr;
