@@ -257,6 +257,19 @@ def main():
         dom_ms = max(tim["vpass0_ms"], tim["hpass0_ms"]) / max(1, tim["launches"])
         per_launch = tim["candidates"] / max(1, tim["launches"])
         achieved = ALGO_BYTES_PER_CANDIDATE * per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # HBM bytes of the dominant kernel per launch, from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as the
+        # gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE), scaled to this run's candidates per launch; counters
+        # cannot be collected from inside the benchmark, so this is null for kernels without a committed measurement
+        traffic, traffic_src = None, None
+        try:
+            pmc_file = os.path.join(ROOT, "profiles", "r1_e_pmc_hbm_rgb_batch1024.json")
+            if sparse and args.config == "rgb":
+                pmc = json.load(open(pmc_file))["counters"]
+                key = "snes::" + dom
+                traffic = (2.0 * pmc["FETCH_SIZE"][key]["max_KB"] + pmc["WRITE_SIZE"][key]["max_KB"]) * 1024.0 * per_launch / 1024.0
+                traffic_src = "profiles/r1_e_pmc_hbm_rgb_batch1024.json (measured per 1,024-candidate launch, scaled)"
+        except (OSError, KeyError, ValueError):
+            traffic = None
         out = {
             "metric": "candidate palettes scored/sec", "value": value, "unit": "candidates/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -268,7 +281,7 @@ def main():
                                        " (%d per GPU)" % args.batch if world > 1 and args.scaling == "weak" else ""),
                        "batch": args.batch, "candidates_per_step": n_total, "config": args.config, "final_error": err},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_candidate": ALGO_BYTES_PER_CANDIDATE, "candidates_per_launch": per_launch,
                          "avg_launch_ms": dom_ms, "group_ms": tim["group_ms"] / max(1, tim["launches"]),
                          "pipeline_achieved": value / world * ALGO_BYTES_PER_CANDIDATE / 1e9,
