@@ -72,7 +72,8 @@ def bench_images(args, torch, dist, S, world, rank, local_rank, device, force_di
 
     sub_count, sub_size = 8, 15
     mine = shard_images(args.images * world, rank, world)
-    batch = ImageBatch.synthetic(mine, sub_count, sub_size, device=local_rank, candidates=args.batch, host_threads=args.host_threads)
+    batch = ImageBatch.synthetic(mine, sub_count, sub_size, device=local_rank, candidates=args.batch, host_threads=args.host_threads,
+                                 batched=not args.per_image_launches)
     batch.initialize()  # untimed: TileAssignment + Clustering of every image
     batch.run(args.warmup)
     torch.cuda.synchronize()
@@ -101,6 +102,7 @@ def bench_images(args, torch, dist, S, world, rank, local_rank, device, force_di
                                    "RGB redmean distance, no dither, %d candidates per optimizer call per image, one call on every "
                                    "image per step, remap + SSIMULACRA2 per candidate, no collective" % (len(mine), args.batch),
                        "images_per_gpu": len(mine), "batch": args.batch, "config": "images", "host_threads": args.host_threads,
+                       "launches": "per image" if args.per_image_launches else "one per stage for all images",
                        "mean_final_error": sum(errs) / len(errs)},
             "roofline": {"bound": "hbm", "kernel": "pipeline (kernels of different images overlap; no per-kernel timing in this mode)",
                          "achieved": value / world * ALGO_BYTES_PER_CANDIDATE / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -124,6 +126,8 @@ def main():
                          "(lib.rs:205) for --config images")
     ap.add_argument("--images", type=int, default=128, help="--config images: images per GPU (1,024 over 8 GPUs)")
     ap.add_argument("--host-threads", type=int, default=8, help="--config images: host threads enqueueing optimizer calls")
+    ap.add_argument("--per-image-launches", action="store_true",
+                    help="--config images: one stream and one set of launches per image instead of one launch per stage for all images")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--config", choices=["rgb", "perceptual", "dither", "images"], default="rgb")
     ap.add_argument("--chunk", type=int, default=0, help="candidates per launch group (0 = library default)")

@@ -98,6 +98,21 @@ int32_t snesimage_step_begin(snesimage_ctx *ctx, uint32_t method, uint32_t palet
                              uint32_t shard_rank, uint32_t shard_count, double *d_errors);
 int32_t snesimage_step_commit(snesimage_ctx *ctx, const double *d_errors);
 
+/* Throughput mode — many independent images on one device, one launch per stage of an optimizer call
+ * for all of them (the reference runs one image per process: `run()` lib.rs:830-1024 once per file).
+ * A batch borrows its contexts (same device, image size, palette geometry and chunk; RGB distance,
+ * no dither): snesimage_batch_step_async is snesimage_step_async for every member — same slot and
+ * method, candidate stream of member i keyed (seeds[i], step_id), at most `chunk` candidates — enqueued
+ * on the batch's stream.  Any other call on a member context first waits for that stream.  The batch
+ * does not own the contexts: destroy it before them. */
+typedef struct snesimage_batch snesimage_batch;
+int32_t snesimage_batch_create(snesimage_ctx **ctxs, uint32_t n, snesimage_batch **out);
+void snesimage_batch_destroy(snesimage_batch *batch);
+int32_t snesimage_batch_step_async(snesimage_batch *batch, uint32_t method, uint32_t palette, uint32_t index,
+                                   uint32_t channel, const uint64_t *seeds /*n*/, uint64_t step_id,
+                                   uint32_t n_random);
+int32_t snesimage_batch_sync(snesimage_batch *batch);
+
 /* State access (the reference mutates these fields directly: lib.rs:1015 and the GUI). */
 int32_t snesimage_get_tile_palettes(snesimage_ctx *ctx, uint8_t *out /*1024*/);
 int32_t snesimage_set_tile_palettes(snesimage_ctx *ctx, const uint8_t *in /*1024*/);

@@ -41,6 +41,11 @@ SIGNATURES = [
     ("snesimage_step_begin", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                          C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     ("snesimage_step_commit", C.c_int32, [C.c_void_p, C.c_void_p]),
+    ("snesimage_batch_create", C.c_int32, [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("snesimage_batch_destroy", None, [C.c_void_p]),
+    ("snesimage_batch_step_async", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64),
+                                               C.c_uint64, C.c_uint32]),
+    ("snesimage_batch_sync", C.c_int32, [C.c_void_p]),
     ("snesimage_get_tile_palettes", C.c_int32, [C.c_void_p, _u8p]),
     ("snesimage_set_tile_palettes", C.c_int32, [C.c_void_p, _u8p]),
     ("snesimage_get_palette_rgb5", C.c_int32, [C.c_void_p, _u8p]),

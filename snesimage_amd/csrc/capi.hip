@@ -5,6 +5,7 @@
 #include "kernels_opt.hpp"
 #include "kernels_fast.hpp"
 #include "kernels_sparse.hpp"
+#include "kernels_batch.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -14,6 +15,7 @@
 #include <cstring>
 #include <string>
 #include <utility>
+#include <memory>
 #include <vector>
 
 using namespace snes;
@@ -143,6 +145,8 @@ struct snesimage_ctx {
     uint8_t *d_dummy_cand = nullptr;
     // k-means workspace
     KmeansWork km{};
+
+    struct snesimage_batch *owner = nullptr; // set while the context is lent to a batch (batch_host.inc)
 
     // cache keys
     bool tables_valid = false, src_valid = false, inc_valid = false;
@@ -589,7 +593,8 @@ int32_t check_slot(snesimage_ctx *c, uint32_t palette, uint32_t index) {
     return SNES_OK;
 }
 
-int32_t set_device(snesimage_ctx *c) { HIPCHK(hipSetDevice(c->device)); return SNES_OK; }
+int32_t batch_quiesce(struct snesimage_batch *b);
+int32_t set_device(snesimage_ctx *c) { HIPCHK(hipSetDevice(c->device)); return c->owner ? batch_quiesce(c->owner) : SNES_OK; }
 
 int32_t drain_timing(snesimage_ctx *c) {
     for (auto &r : c->t_pending) {
@@ -1124,3 +1129,5 @@ int32_t snesimage_debug_math(int32_t device, int32_t op, const float *x, const f
 }
 
 } // extern "C"
+
+#include "batch_host.inc"

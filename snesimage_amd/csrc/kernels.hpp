@@ -81,7 +81,7 @@ __global__ void k_palette_tables(const uint8_t *__restrict__ colors /*ncol*3 raw
 }
 
 // Per candidate: 8-bit expansion, linear RGB, positive XYB.  cand_tab[k] = {lin r,g,b, X,Y,B, rgb8 bits, 0}
-__global__ void k_candidate_tables(const uint8_t *__restrict__ rgb5, int n, const float *__restrict__ eotf, float *__restrict__ cand_tab) {
+__device__ __forceinline__ void candidate_tables_body(const uint8_t *__restrict__ rgb5, int n, const float *__restrict__ eotf, float *__restrict__ cand_tab) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     uint32_t rgb8 = rgb5_to_rgb8(rgb5[3 * k], rgb5[3 * k + 1], rgb5[3 * k + 2]);
@@ -111,7 +111,7 @@ struct PrepParams {
     int *zero; int nzero; // counters of the group-sparse path that belong to this pack: cleared here instead of by memset launches
 };
 
-__global__ __launch_bounds__(256) void k_prep(PrepParams P) {
+__device__ __forceinline__ void prep_body(const PrepParams &P) {
     if (P.zero && blockIdx.x == 0 && (int)threadIdx.x < P.nzero) P.zero[threadIdx.x] = 0;
     __shared__ uint32_t s_rgb8[256];
     __shared__ float s_lab[256 * 3];
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(256) void k_vpass(VParams P) {
 }
 
 // Msssim::score + `100 - score` (lib.rs:547).  One thread per candidate.
-__global__ void k_final_score(const double *__restrict__ part, int ncand, Geom G, double *__restrict__ errors, int err_stride, int err_offset, int *__restrict__ zero = nullptr, int nzero = 0) {
+__device__ __forceinline__ void final_score_body(const double *__restrict__ part, int ncand, const Geom &G, double *__restrict__ errors, int err_stride, int err_offset, int *__restrict__ zero, int nzero) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (zero && c < nzero) zero[c] = 0; // the launch group's work-item counters, ready for the lane's next chunk
     if (c >= ncand) return;
@@ -706,6 +706,13 @@ __global__ void k_final_score(const double *__restrict__ part, int ncand, Geom G
     if (ssim > 0.0) ssim = fma(pow(ssim, 0.6276336467831387), -10.0, 100.0);
     else ssim = 100.0;
     errors[(size_t)err_offset + (size_t)c * err_stride] = 100.0 - ssim;
+}
+
+// ---- kernel entry points of the bodies above (kernels_batch.hpp holds the many-images flavours) ----
+__global__ void k_candidate_tables(const uint8_t *__restrict__ rgb5, int n, const float *__restrict__ eotf, float *__restrict__ cand_tab) { candidate_tables_body(rgb5, n, eotf, cand_tab); }
+__global__ __launch_bounds__(256) void k_prep(PrepParams P) { prep_body(P); }
+__global__ void k_final_score(const double *__restrict__ part, int ncand, Geom G, double *__restrict__ errors, int err_stride, int err_offset, int *__restrict__ zero = nullptr, int nzero = 0) {
+    final_score_body(part, ncand, G, errors, err_stride, err_offset, zero, nzero);
 }
 
 } // namespace snes

@@ -1,0 +1,36 @@
+// snesimage_amd/csrc/kernels_batch.hpp — one launch over many images (throughput mode).
+// The kernels of an optimizer call are the single-image bodies unchanged; blockIdx.z picks the image, whose
+// arguments sit in a device array instead of the kernel's own argument block.  Every image of a batch has the same
+// geometry and the same number of candidates, so one grid shape serves them all; nothing is shared between images.
+#pragma once
+#include "kernels_sparse.hpp"
+
+namespace snes {
+
+struct BatchArgs {
+    SparseParams Pc, Pb; // the call's candidates / the base image B of the call's slot
+    PrepParams prep;     // pack of the slot (mode 2)
+    unsigned long long key; const uint8_t *colors_in; uint8_t *colors; uint8_t *cand; const float *eotf; float *cand_tab;
+    const double *part; double *errors; double *inc_err; StepResult *last; PaletteTables T;
+    int method, n, slot, channel, nes, npx;
+};
+
+#define SNES_BATCH_IMG const BatchArgs &a = A[blockIdx.z]
+__global__ void kb_gen_candidates(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; gen_candidates_body(a.method, a.n, a.key, a.colors_in, a.slot, a.channel, a.cand, 0, 1, nullptr, nullptr); }
+__global__ __launch_bounds__(256) void kb_prep(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; prep_body(a.prep); }
+__global__ __launch_bounds__(256) void kb_build_plist(const BatchArgs *__restrict__ A) {
+    SNES_BATCH_IMG;
+    build_plist_body(a.Pb.pack, a.npx, const_cast<uint4 *>(a.Pb.plist), const_cast<int *>(a.Pb.plist_count));
+}
+__global__ __launch_bounds__(1024) void kb_sparse_scan(const BatchArgs *__restrict__ A, int base) { SNES_BATCH_IMG; sparse_scan_body(base ? a.Pb : a.Pc); }
+__global__ __launch_bounds__(256) void kb_base_down(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; base_down_body(a.Pb); }
+__global__ __launch_bounds__(256) void kb_sparse_down(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; sparse_down_body(a.Pc, 0); }
+__global__ void kb_candidate_tables(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; candidate_tables_body(a.cand, a.n, a.eotf, a.cand_tab); }
+__global__ __launch_bounds__(64) void kb_sparse_h(const BatchArgs *__restrict__ A, int base) { SNES_BATCH_IMG; sparse_h_body(base ? a.Pb : a.Pc); }
+__global__ __launch_bounds__(256, 1) void kb_sparse_v_base(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; sparse_v_base_body(a.Pb); }
+__global__ __launch_bounds__(256, 4) void kb_sparse_v(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; sparse_v_body<false, 2, 2>(a.Pc, (int)blockIdx.y); }
+__global__ void kb_final_score(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; final_score_body(a.part, a.n, a.Pc.G, a.errors, 1, 0, a.Pc.item_count, (int)kMaxScales); }
+__global__ __launch_bounds__(256) void kb_commit(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; commit_body(a.errors, a.n, a.cand, a.colors, a.slot, a.nes, a.inc_err, a.last, a.T); }
+#undef SNES_BATCH_IMG
+
+} // namespace snes

@@ -281,8 +281,8 @@ __device__ __forceinline__ unsigned long long dev_mix64(unsigned long long z) {
 // channel of the current colour (lib.rs:296-297); 2: the NES table (lib.rs:252-253)
 // With `sel`: also the shard's own list (candidate k belongs to rank k % count, position k / count) and the error vector
 // preset to +inf — what k_shard_select does for an explicit list.
-__global__ void k_gen_candidates(int method, int n, unsigned long long key, const uint8_t *__restrict__ colors, int slot, int channel, uint8_t *__restrict__ cand,
-                                 int rank = 0, int count = 1, uint8_t *__restrict__ sel = nullptr, double *__restrict__ errors = nullptr) {
+__device__ __forceinline__ void gen_candidates_body(int method, int n, unsigned long long key, const uint8_t *__restrict__ colors, int slot, int channel, uint8_t *__restrict__ cand,
+                                                    int rank, int count, uint8_t *__restrict__ sel, double *__restrict__ errors) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     uint8_t c[3];
@@ -313,8 +313,8 @@ __global__ void k_shard_select(const uint8_t *__restrict__ cand, int n, int rank
 // Acceptance rule: ascending k, strict `<` against the running best starting from the incumbent
 // (lib.rs:216-219, 302-305) or from f64::MAX for the NES method (lib.rs:250, 258-261).
 struct PaletteTables { const float *eotf, *lab_eotf; uint32_t *rgb8; float *lin, *xyb, *lab; }; // lab == nullptr without --perceptual-palettes
-__global__ __launch_bounds__(256) void k_commit(const double *__restrict__ errors, int n, const uint8_t *__restrict__ cand, uint8_t *__restrict__ colors, int slot, int nes, double *__restrict__ inc_err,
-                                               StepResult *__restrict__ last, PaletteTables T) {
+__device__ __forceinline__ void commit_body(const double *__restrict__ errors, int n, const uint8_t *__restrict__ cand, uint8_t *__restrict__ colors, int slot, int nes, double *__restrict__ inc_err,
+                                            StepResult *__restrict__ last, const PaletteTables &T) {
     // The sequential scan "for k ascending: if e_k < best" ends on the FIRST index attaining the minimum, provided that
     // minimum is < the starting value; a parallel (error, index) lexicographic minimum gives the same answer.
     __shared__ double s_e[256];
@@ -521,6 +521,16 @@ __global__ void k_gather_points(const uint8_t *__restrict__ orig, const float *_
     uint32_t px = index[i];
     if (perceptual) { pts[3 * i] = (double)labpx[3 * (size_t)px]; pts[3 * i + 1] = (double)labpx[3 * (size_t)px + 1]; pts[3 * i + 2] = (double)labpx[3 * (size_t)px + 2]; }
     else { uint32_t o = reinterpret_cast<const uint32_t *>(orig)[px]; pts[3 * i] = (double)(o & 0xff); pts[3 * i + 1] = (double)((o >> 8) & 0xff); pts[3 * i + 2] = (double)((o >> 16) & 0xff); }
+}
+
+// ---- kernel entry points of the bodies above ----
+__global__ void k_gen_candidates(int method, int n, unsigned long long key, const uint8_t *__restrict__ colors, int slot, int channel, uint8_t *__restrict__ cand,
+                                 int rank = 0, int count = 1, uint8_t *__restrict__ sel = nullptr, double *__restrict__ errors = nullptr) {
+    gen_candidates_body(method, n, key, colors, slot, channel, cand, rank, count, sel, errors);
+}
+__global__ __launch_bounds__(256) void k_commit(const double *__restrict__ errors, int n, const uint8_t *__restrict__ cand, uint8_t *__restrict__ colors, int slot, int nes, double *__restrict__ inc_err,
+                                               StepResult *__restrict__ last, PaletteTables T) {
+    commit_body(errors, n, cand, colors, slot, nes, inc_err, last, T);
 }
 
 } // namespace snes

@@ -157,7 +157,7 @@ __device__ __forceinline__ unsigned long long pair_or_compress(unsigned long lon
     return m;
 }
 constexpr int kScanTile = 6144; // contested pixels staged in LDS per pass (the BASELINE slot has ~6.8 k)
-__global__ __launch_bounds__(1024) void k_sparse_scan(SparseParams P) {
+__device__ __forceinline__ void sparse_scan_body(const SparseParams &P) {
     // 16 waves = 16 candidates per block share one LDS copy of the slot's contested-pixel list
     __shared__ uint32_t s_rgb[kScanTile], s_thr[kScanTile];
     __shared__ unsigned short s_px[kScanTile]; // x | (y>>2) << 8 would lose x precision: keep x (8 bit) and group (6 bit)
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(1024) void k_sparse_scan(SparseParams P) {
 // ---- downscale chain + XYB on changed groups only -------------------------------------------------------
 // base: grid.x blocks share the rows of each scale (launched once per scale, P.ncand = scale to do);
 // candidates: one block per candidate walks the scales itself.
-__global__ __launch_bounds__(256) void k_sparse_down(SparseParams P, int only_scale) {
+__device__ __forceinline__ void sparse_down_body(const SparseParams &P, int only_scale) {
     __shared__ float s_lin[256 * 3];
     const Geom &G = P.G;
     const int t = threadIdx.x;
@@ -322,7 +322,7 @@ __device__ __forceinline__ void base_store(const SparseParams &P, float *mine, i
         orr[(size_t)c * 4 * Ws + (size_t)X * 4 + r] = xyb[c];
     }
 }
-__global__ __launch_bounds__(256) void k_base_down(SparseParams P) {
+__device__ __forceinline__ void base_down_body(const SparseParams &P) {
     __shared__ float s_lin[256 * 3];
     __shared__ float l1[3][16][17], l2[3][8][9], l3[3][4][5], l4[3][2][3];
     const Geom &G = P.G;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void k_base_down(SparseParams P) {
     }
 
 // ---- H pass of changed groups: one lane quad = the four rows of one (candidate, group slot, channel) ----
-__global__ __launch_bounds__(64) void k_sparse_h(SparseParams P) {
+__device__ __forceinline__ void sparse_h_body(const SparseParams &P) {
     __shared__ float s_lut[3][256];
     __shared__ float s_tr[3][64 * 5];
     const Geom &G = P.G;
@@ -758,7 +758,7 @@ __device__ __forceinline__ void sparse_v_body(const SparseParams &P, const int s
 // candidates: every scale in one launch, flags decided at run time (see sparse_v_body)
 __global__ __launch_bounds__(256, 4) void k_sparse_v(SparseParams P) { sparse_v_body<false, 2, 2>(P, (int)blockIdx.y); }
 // B: one launch as well, each scale in its specialised flavour
-__global__ __launch_bounds__(256, 1) void k_sparse_v_base(SparseParams P) {
+__device__ __forceinline__ void sparse_v_base_body(const SparseParams &P) {
     const int s = (int)blockIdx.y;
     if (s >= P.G.nscales) return;
     if (s == 0) { if (P.G.sw[0] >= 64) sparse_v_body<true, 1, 1>(P, 0); else sparse_v_body<false, 1, 1>(P, 0); }
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256, 1) void k_sparse_v_base(SparseParams P) {
 #undef SNES_VSTEP
 
 // contested pixels of a slot (thr != 0) -> compact list, built once per slot
-__global__ __launch_bounds__(256) void k_build_plist(const unsigned long long *__restrict__ pack, int npx, uint4 *__restrict__ plist, int *__restrict__ count) {
+__device__ __forceinline__ void build_plist_body(const unsigned long long *__restrict__ pack, int npx, uint4 *__restrict__ plist, int *__restrict__ count) {
     int px = blockIdx.x * blockDim.x + threadIdx.x;
     if (px >= npx) return;
     const unsigned long long w = pack[px];
@@ -779,5 +779,13 @@ __global__ __launch_bounds__(256) void k_build_plist(const unsigned long long *_
         plist[i] = make_uint4((uint32_t)px, (uint32_t)w & 0x00ffffffu, thr, 0u);
     }
 }
+
+// ---- kernel entry points of the bodies above ----
+__global__ __launch_bounds__(1024) void k_sparse_scan(SparseParams P) { sparse_scan_body(P); }
+__global__ __launch_bounds__(256) void k_sparse_down(SparseParams P, int only_scale) { sparse_down_body(P, only_scale); }
+__global__ __launch_bounds__(256) void k_base_down(SparseParams P) { base_down_body(P); }
+__global__ __launch_bounds__(64) void k_sparse_h(SparseParams P) { sparse_h_body(P); }
+__global__ __launch_bounds__(256, 1) void k_sparse_v_base(SparseParams P) { sparse_v_base_body(P); }
+__global__ __launch_bounds__(256) void k_build_plist(const unsigned long long *__restrict__ pack, int npx, uint4 *__restrict__ plist, int *__restrict__ count) { build_plist_body(pack, npx, plist, count); }
 
 } // namespace snes

@@ -8,9 +8,10 @@ device) by a few host threads — ctypes drops the GIL for the duration of each 
 overlaps them.  Across GPUs the images are split into contiguous blocks (`shard_images`); there is
 no collective in this mode.
 """
+import ctypes as C
 import threading
 
-from . import api
+from . import _ffi, api
 from .synth import synth_image
 
 IMAGE_SEED0 = 0x5EED0000  # image i of a batch is synth_image(IMAGE_SEED0 + i) (SURVEY §8d)
@@ -29,8 +30,9 @@ class ImageBatch:
     """`images`: iterable of (global_index, rgba) pairs, all optimised with the same palette geometry and flags."""
 
     def __init__(self, images, sub_count, sub_size, device=0, candidates=64, host_threads=8, dither=False,
-                 perceptual=False, nes=False):
+                 perceptual=False, nes=False, batched=False):
         self.sub_count, self.sub_size, self.candidates, self.nes = int(sub_count), int(sub_size), int(candidates), bool(nes)
+        self.batched, self._batch = bool(batched), None
         self.ids = []
         self.images = []
         for gid, rgba in images:
@@ -73,12 +75,34 @@ class ImageBatch:
                 self.images[i].initialize_tiles()
                 self.images[i].recalculate_palettes()
         self._parallel(init)
+        if self.batched:
+            self._open_batch()
+
+    def _open_batch(self):
+        L = _ffi.load()
+        arr = (C.c_void_p * len(self.images))(*[img._c for img in self.images])
+        h = C.c_void_p()
+        rc = L.snesimage_batch_create(arr, len(self.images), C.byref(h))
+        if rc != 0:
+            raise api.SnesImageError(rc, L.snesimage_last_error().decode())
+        self._batch = h
+        self._seeds = (C.c_uint64 * len(self.images))(*[1 + gid for gid in self.ids])
 
     def run(self, n_calls):
         """Enqueue the next `n_calls` optimizer calls of the reference's slot schedule (lib.rs:881-933) for every image,
         then wait for the device.  Candidate streams are keyed (1 + image index, call number)."""
         sched = api.schedule(self.sub_count, self.sub_size, self.calls_done + n_calls, nes=self.nes)[self.calls_done:]
         first = self.calls_done
+        if self._batch is not None:  # one call = one launch per stage for all images
+            L = _ffi.load()
+            for j, (method, p, idx, ch, _) in enumerate(sched):
+                rc = L.snesimage_batch_step_async(self._batch, method, p, idx, ch, self._seeds, first + j,
+                                                  self.candidates if method == api.METHOD_RANDOM else 0)
+                if rc != 0:
+                    raise api.SnesImageError(rc, L.snesimage_last_error().decode())
+            self.sync()
+            self.calls_done += n_calls
+            return
 
         def go(mine):  # breadth first: call j of every image before call j+1 of any, so all streams stay populated
             for j, (method, p, idx, ch, _) in enumerate(sched):
@@ -90,6 +114,10 @@ class ImageBatch:
         self.calls_done += n_calls
 
     def sync(self):
+        if self._batch is not None:
+            rc = _ffi.load().snesimage_batch_sync(self._batch)
+            if rc != 0:
+                raise api.SnesImageError(rc, _ffi.load().snesimage_last_error().decode())
         for img in self.images:
             img.sync()
 
@@ -97,6 +125,9 @@ class ImageBatch:
         return [img.last_step()[0] for img in self.images]
 
     def close(self):
+        if self._batch is not None:
+            _ffi.load().snesimage_batch_destroy(self._batch)
+            self._batch = None
         for img in self.images:
             img.close()
         self.images = []

@@ -17,15 +17,16 @@ def test_shard_images_is_a_partition(n, world):
 
 
 @pytest.mark.gpu
-def test_concurrent_images_equal_one_at_a_time():
-    """Optimizer calls of several images enqueued side by side from several host threads give, for every image, exactly
-    the state that stepping that image alone gives."""
+@pytest.mark.parametrize("batched", [False, True])
+def test_concurrent_images_equal_one_at_a_time(batched):
+    """Optimizer calls of several images — enqueued side by side from several host threads, or issued as one launch per
+    stage for all of them — give, for every image, exactly the state that stepping that image alone gives."""
     import snesimage_amd as S
     from snesimage_amd.synth import synth_image
     from snesimage_amd.throughput import IMAGE_SEED0, ImageBatch
 
     ids = [5, 6, 7, 900]
-    batch = ImageBatch.synthetic(ids, 4, 7, candidates=24, host_threads=3)
+    batch = ImageBatch.synthetic(ids, 4, 7, candidates=24, host_threads=3, batched=batched)
     batch.initialize()
     batch.run(3)
     batch.run(4)  # the schedule continues where the first run stopped
@@ -42,3 +43,15 @@ def test_concurrent_images_equal_one_at_a_time():
         assert batch.errors()[pos] == e
         solo.close()
     batch.close()
+
+
+@pytest.mark.gpu
+def test_batch_rejects_what_it_does_not_cover():
+    import snesimage_amd as S
+    from snesimage_amd.throughput import ImageBatch
+    for flags in ({"dither": True}, {"perceptual": True}):
+        b = ImageBatch.synthetic([1, 2], 2, 3, candidates=8, batched=True, **flags)
+        with pytest.raises(S.SnesImageError) as e:
+            b.initialize()
+        assert e.value.code == -5
+        b.close()
