@@ -73,7 +73,7 @@ def bench_images(args, torch, dist, S, world, rank, local_rank, device, force_di
     sub_count, sub_size = 8, 15
     mine = shard_images(args.images * world, rank, world)
     batch = ImageBatch.synthetic(mine, sub_count, sub_size, device=local_rank, candidates=args.batch, host_threads=args.host_threads,
-                                 batched=not args.per_image_launches)
+                                 batched=not args.per_image_launches, groups=args.groups)
     batch.initialize()  # untimed: TileAssignment + Clustering of every image
     batch.run(args.warmup)
     torch.cuda.synchronize()
@@ -126,6 +126,7 @@ def main():
                          "(lib.rs:205) for --config images")
     ap.add_argument("--images", type=int, default=128, help="--config images: images per GPU (1,024 over 8 GPUs)")
     ap.add_argument("--host-threads", type=int, default=8, help="--config images: host threads enqueueing optimizer calls")
+    ap.add_argument("--groups", type=int, default=4, help="--config images: batches stepped side by side on their own streams")
     ap.add_argument("--per-image-launches", action="store_true",
                     help="--config images: one stream and one set of launches per image instead of one launch per stage for all images")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")

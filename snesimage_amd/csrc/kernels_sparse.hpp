@@ -770,14 +770,19 @@ __device__ __forceinline__ void sparse_v_base_body(const SparseParams &P) {
 
 // contested pixels of a slot (thr != 0) -> compact list, built once per slot
 __device__ __forceinline__ void build_plist_body(const unsigned long long *__restrict__ pack, int npx, uint4 *__restrict__ plist, int *__restrict__ count) {
-    int px = blockIdx.x * blockDim.x + threadIdx.x;
-    if (px >= npx) return;
-    const unsigned long long w = pack[px];
+    const int px = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long w = 0;
+    if (px < npx) w = pack[px];
     const uint32_t thr = (uint32_t)(w >> 32);
-    if (thr != 0u) {
-        const int i = atomicAdd(count, 1);
-        plist[i] = make_uint4((uint32_t)px, (uint32_t)w & 0x00ffffffu, thr, 0u);
-    }
+    const bool hit = thr != 0u;
+    // one atomic per wave: the leader reserves the wave's entries, each contested lane takes its rank among them
+    const unsigned long long m = __ballot(hit);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, leader);
+    if (hit) plist[base + __popcll(m & ((1ull << lane) - 1ull))] = make_uint4((uint32_t)px, (uint32_t)w & 0x00ffffffu, thr, 0u);
 }
 
 // ---- kernel entry points of the bodies above ----

@@ -30,9 +30,9 @@ class ImageBatch:
     """`images`: iterable of (global_index, rgba) pairs, all optimised with the same palette geometry and flags."""
 
     def __init__(self, images, sub_count, sub_size, device=0, candidates=64, host_threads=8, dither=False,
-                 perceptual=False, nes=False, batched=False):
+                 perceptual=False, nes=False, batched=False, groups=4):
         self.sub_count, self.sub_size, self.candidates, self.nes = int(sub_count), int(sub_size), int(candidates), bool(nes)
-        self.batched, self._batch = bool(batched), None
+        self.batched, self._batches, self.groups = bool(batched), [], max(1, int(groups))
         self.ids = []
         self.images = []
         for gid, rgba in images:
@@ -79,27 +79,32 @@ class ImageBatch:
             self._open_batch()
 
     def _open_batch(self):
+        """`groups` library batches over interleaved halves (thirds, ...) of the images: each has its own stream, so the
+        latency-bound stages of one group's call run beside the VALU-bound ones of another's."""
         L = _ffi.load()
-        arr = (C.c_void_p * len(self.images))(*[img._c for img in self.images])
-        h = C.c_void_p()
-        rc = L.snesimage_batch_create(arr, len(self.images), C.byref(h))
-        if rc != 0:
-            raise api.SnesImageError(rc, L.snesimage_last_error().decode())
-        self._batch = h
-        self._seeds = (C.c_uint64 * len(self.images))(*[1 + gid for gid in self.ids])
+        g = min(self.groups, len(self.images))
+        for k in range(g):
+            pos = list(range(k, len(self.images), g))
+            arr = (C.c_void_p * len(pos))(*[self.images[i]._c for i in pos])
+            h = C.c_void_p()
+            rc = L.snesimage_batch_create(arr, len(pos), C.byref(h))
+            if rc != 0:
+                raise api.SnesImageError(rc, L.snesimage_last_error().decode())
+            self._batches.append((h, (C.c_uint64 * len(pos))(*[1 + self.ids[i] for i in pos])))
 
     def run(self, n_calls):
         """Enqueue the next `n_calls` optimizer calls of the reference's slot schedule (lib.rs:881-933) for every image,
         then wait for the device.  Candidate streams are keyed (1 + image index, call number)."""
         sched = api.schedule(self.sub_count, self.sub_size, self.calls_done + n_calls, nes=self.nes)[self.calls_done:]
         first = self.calls_done
-        if self._batch is not None:  # one call = one launch per stage for all images
+        if self._batches:  # one call = one launch per stage for all images of a group
             L = _ffi.load()
             for j, (method, p, idx, ch, _) in enumerate(sched):
-                rc = L.snesimage_batch_step_async(self._batch, method, p, idx, ch, self._seeds, first + j,
-                                                  self.candidates if method == api.METHOD_RANDOM else 0)
-                if rc != 0:
-                    raise api.SnesImageError(rc, L.snesimage_last_error().decode())
+                for h, seeds in self._batches:
+                    rc = L.snesimage_batch_step_async(h, method, p, idx, ch, seeds, first + j,
+                                                      self.candidates if method == api.METHOD_RANDOM else 0)
+                    if rc != 0:
+                        raise api.SnesImageError(rc, L.snesimage_last_error().decode())
             self.sync()
             self.calls_done += n_calls
             return
@@ -114,8 +119,8 @@ class ImageBatch:
         self.calls_done += n_calls
 
     def sync(self):
-        if self._batch is not None:
-            rc = _ffi.load().snesimage_batch_sync(self._batch)
+        for h, _ in self._batches:
+            rc = _ffi.load().snesimage_batch_sync(h)
             if rc != 0:
                 raise api.SnesImageError(rc, _ffi.load().snesimage_last_error().decode())
         for img in self.images:
@@ -125,9 +130,9 @@ class ImageBatch:
         return [img.last_step()[0] for img in self.images]
 
     def close(self):
-        if self._batch is not None:
-            _ffi.load().snesimage_batch_destroy(self._batch)
-            self._batch = None
+        for h, _ in self._batches:
+            _ffi.load().snesimage_batch_destroy(h)
+        self._batches = []
         for img in self.images:
             img.close()
         self.images = []
