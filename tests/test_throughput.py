@@ -55,3 +55,32 @@ def test_batch_rejects_what_it_does_not_cover():
             b.initialize()
         assert e.value.code == -5
         b.close()
+
+
+@pytest.mark.gpu
+def test_batched_channel_calls_and_implicit_sync():
+    """The batched form through random AND channel calls of the reference's schedule (2 x 3 entries: calls 24.. are the
+    channel sweeps), read back through a member context without an explicit sync."""
+    import snesimage_amd as S
+    from snesimage_amd import _ffi
+    from snesimage_amd.synth import synth_image
+    from snesimage_amd.throughput import IMAGE_SEED0, ImageBatch
+
+    ids = [11, 12, 13]
+    batch = ImageBatch.synthetic(ids, 2, 3, candidates=10, batched=True, groups=2)
+    batch.initialize()
+    L = _ffi.load()
+    sched = S.schedule(2, 3, 30)
+    for j, (method, p, idx, ch, _) in enumerate(sched):  # enqueue only: no sync anywhere
+        for h, seeds in batch._batches:
+            assert L.snesimage_batch_step_async(h, method, p, idx, ch, seeds, j, 10 if method == S.METHOD_RANDOM else 0) == 0
+    got = [(img.palette.copy(), img.palette_map.copy(), img.last_step()[0]) for img in batch.images]  # waits for the batch's stream
+    for pos, gid in enumerate(ids):
+        solo = S.OptimizedImage(synth_image(IMAGE_SEED0 + gid), 2, 3)
+        solo.initialize_tiles()
+        solo.recalculate_palettes()
+        for j, (method, p, idx, ch, _) in enumerate(sched):
+            e, _ = solo.step(method, p, idx, ch, 1 + gid, j, 10 if method == S.METHOD_RANDOM else 0)
+        assert np.array_equal(got[pos][0], solo.palette) and np.array_equal(got[pos][1], solo.palette_map) and got[pos][2] == e
+        solo.close()
+    batch.close()
