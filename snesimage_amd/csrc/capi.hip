@@ -767,9 +767,11 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     return SNES_OK;
 }
 
+void batch_forget(struct snesimage_batch *b, snesimage_ctx *c);
 void snesimage_destroy(snesimage_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->owner) batch_forget(c->owner, c); // waits for the batch's stream and retires the batch
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)drain_timing(c);
     dfree(c->d_packC4); dfree(c->d_packR4); dfree(c->d_subC4); dfree(c->d_subR4); dfree(c->d_mapsC4); dfree(c->d_mapsR4); dfree(c->d_img1C4); dfree(c->d_img1R4); dfree(c->d_mu1R4); dfree(c->d_s11R4);

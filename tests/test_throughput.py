@@ -84,3 +84,20 @@ def test_batched_channel_calls_and_implicit_sync():
         assert np.array_equal(got[pos][0], solo.palette) and np.array_equal(got[pos][1], solo.palette_map) and got[pos][2] == e
         solo.close()
     batch.close()
+
+
+@pytest.mark.gpu
+def test_destroying_a_member_context_retires_the_batch():
+    import snesimage_amd as S
+    from snesimage_amd import _ffi
+    from snesimage_amd.throughput import ImageBatch
+    batch = ImageBatch.synthetic([21, 22], 2, 3, candidates=8, batched=True, groups=1)
+    batch.initialize()
+    batch.run(2)
+    batch.images[1].close()  # while lent to the batch
+    L = _ffi.load()
+    h, seeds = batch._batches[0]
+    assert L.snesimage_batch_step_async(h, 0, 0, 0, 0, seeds, 2, 8) == -3
+    assert b"destroyed" in L.snesimage_last_error()
+    batch.images[0].step(S.METHOD_RANDOM, 0, 0, 0, 1, 2, 8)  # the surviving context is its own again
+    batch.close()
