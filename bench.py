@@ -225,7 +225,7 @@ def main():
         ms = ev0.elapsed_time(ev1) / reps
         rate = n_r / (ms * 1e-3)
         remap = {"value": rate, "unit": "candidates/s", "candidates": n_r, "ms": ms,
-                 "kernel": "k_dither" if flags & S.DITHER else "k_remap4",
+                 "kernel": "k_dither" if flags & S.DITHER else ("k_remap_fill4 + k_remap_won_lab" if flags & S.PERCEPTUAL else "k_remap4"),
                  "algorithmic_GBps": rate * ALGO_BYTES_PER_CANDIDATE / 1e9, "frac_of_hbm_peak": rate * ALGO_BYTES_PER_CANDIDATE / 1e9 / HBM_PEAK_GBS,
                  "map_write_GBps": rate * 65536 / 1e9,
                  "note": "source pixels (as the 512 KiB per-slot pack), tile map and palette are cache-resident across candidates: "

@@ -119,6 +119,7 @@ struct snesimage_ctx {
     // dither path: every lane keeps the map of the best candidate it has scored in the current list, so that the commit
     // takes the winner's map instead of dithering the image again (lib.rs:237 re-runs optimize() on the winner's palette)
     uint8_t *d_bestmap = nullptr, *d_bestmaps_all = nullptr; BestRec *d_bestrec = nullptr, *d_bestrecs_all = nullptr; int *d_skip = nullptr;
+    uint4 *d_rplist = nullptr; int *d_rcount = nullptr; // contested pixels for the perceptual remap-only entry point
     bool map_pending = false; // without dither the optimize() that ends a step (lib.rs:237) is deferred until something reads palette_map
     bool best_valid = false, map_synced = false; // records belong to the list being committed; d_map is optimize() of the current palette
     // Additional launch lanes: chunk i of a candidate list runs on lane i % nlanes (lane 0 = the context's stream and the
@@ -777,7 +778,7 @@ void snesimage_destroy(snesimage_ctx *c) {
     dfree(c->d_packC4); dfree(c->d_packR4); dfree(c->d_subC4); dfree(c->d_subR4); dfree(c->d_mapsC4); dfree(c->d_mapsR4); dfree(c->d_img1C4); dfree(c->d_img1R4); dfree(c->d_mu1R4); dfree(c->d_s11R4);
     dfree(c->d_orig); dfree(c->d_tile_pal); dfree(c->d_colors); dfree(c->d_map); dfree(c->d_pack); dfree(c->d_packT); dfree(c->d_eotf); dfree(c->d_lab_eotf);
     dfree(c->d_pal_rgb8); dfree(c->d_pal_lin); dfree(c->d_pal_xyb); dfree(c->d_pal_lab); dfree(c->d_lin0); dfree(c->d_img1); dfree(c->d_img1T); dfree(c->d_mu1); dfree(c->d_s11);
-    dfree(c->d_bestmaps_all); dfree(c->d_bestrecs_all); dfree(c->d_skip);
+    dfree(c->d_bestmaps_all); dfree(c->d_bestrecs_all); dfree(c->d_skip); dfree(c->d_rplist); dfree(c->d_rcount);
     dfree(c->d_labpx); dfree(c->d_labpxT); dfree(c->d_work); dfree(c->d_cand_tab); dfree(c->d_cand_lab); dfree(c->d_part); dfree(c->d_maps); dfree(c->d_mapsT);
     dfree(c->d_cand); dfree(c->d_cand_sel); dfree(c->d_errs); dfree(c->d_errs_sel); dfree(c->d_inc_err); dfree(c->d_last); dfree(c->d_scratch_err); dfree(c->d_dummy_cand);
     for (auto &L : c->extra) { if (L.stream) (void)hipStreamSynchronize(L.stream); dfree(L.d_mapsC4); dfree(L.d_mapsR4); dfree(L.d_work); dfree(L.d_cand_tab); dfree(L.d_cand_lab); dfree(L.d_part); dfree(L.d_maps); dfree(L.d_mapsT); if (L.done) (void)hipEventDestroy(L.done); if (L.stream) (void)hipStreamDestroy(L.stream); }
@@ -877,8 +878,15 @@ int32_t snesimage_remap_candidates_device(snesimage_ctx *c, uint32_t palette, ui
             MapsParams M{}; M.pack = c->d_pack; M.cand_tab = c->d_cand_tab; M.cand_lab = c->d_cand_lab; M.labpx = c->d_labpx; M.maps = maps;
             M.npx = (int)c->npx; M.ncol = c->ncol; M.sub_size = (int)c->sub_size; M.si = (int)index; M.ncand = (int)nc; M.perceptual = c->perceptual ? 1 : 0;
             const dim3 grid((unsigned)((c->npx / 4 + 255) / 256), (nc + kRemapCands - 1) / kRemapCands);
-            if (c->perceptual) hipLaunchKernelGGL((k_remap4<true>), grid, dim3(256), 0, c->stream, M);
-            else hipLaunchKernelGGL((k_remap4<false>), grid, dim3(256), 0, c->stream, M);
+            if (c->perceptual) { // B's map for everyone, then the CIEDE2000 win tests over the slot's contested pixels only
+                if (!c->d_rplist) { HIPCHK(hipMalloc(&c->d_rplist, sizeof(uint4) * c->npx)); HIPCHK(hipMalloc(&c->d_rcount, sizeof(int))); }
+                if (c0 == 0) {
+                    HIPCHK(hipMemsetAsync(c->d_rcount, 0, sizeof(int), c->stream));
+                    hipLaunchKernelGGL(k_build_plist, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, c->d_pack, (int)c->npx, c->d_rplist, c->d_rcount);
+                }
+                hipLaunchKernelGGL(k_remap_fill4, grid, dim3(256), 0, c->stream, M);
+                hipLaunchKernelGGL(k_remap_won_lab, dim3((nc + 3) / 4), dim3(256), 0, c->stream, M, (const uint4 *)c->d_rplist, (const int *)c->d_rcount);
+            } else hipLaunchKernelGGL((k_remap4<false>), grid, dim3(256), 0, c->stream, M);
         }
     }
     HIPCHK(hipGetLastError());

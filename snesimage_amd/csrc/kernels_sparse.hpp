@@ -785,6 +785,44 @@ __device__ __forceinline__ void build_plist_body(const unsigned long long *__res
     if (hit) plist[base + __popcll(m & ((1ull << lane) - 1ull))] = make_uint4((uint32_t)px, (uint32_t)w & 0x00ffffffu, thr, 0u);
 }
 
+// ---- the remap alone with --perceptual-palettes (snesimage_remap_candidates_device) -----------------------------
+// CIEDE2000 costs ~250 instructions, and only the contested pixels of the slot (a tenth of the image) need it: every
+// candidate's map starts as B's (k_remap_fill4), then one wave per candidate walks the compact list and overwrites
+// the pixels its colour wins with the slot's index.
+__global__ __launch_bounds__(256) void k_remap_fill4(MapsParams P) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q * 4 >= P.npx) return;
+    const uint4 a = reinterpret_cast<const uint4 *>(P.pack)[2 * (size_t)q], b = reinterpret_cast<const uint4 *>(P.pack)[2 * (size_t)q + 1];
+    const uint32_t lo[4] = {a.x, a.z, b.x, b.z};
+    uint32_t word = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t ci0 = lo[i] >> 24;
+        word |= (ci0 == (uint32_t)P.ncol ? (uint32_t)P.si : (ci0 == (uint32_t)P.ncol + 1u ? 0u : ci0 % (uint32_t)P.sub_size)) << (8 * i);
+    }
+    const int c0 = blockIdx.y * kRemapCands;
+    for (int cc = 0; cc < kRemapCands && c0 + cc < P.ncand; cc++) reinterpret_cast<uint32_t *>(P.maps + (size_t)(c0 + cc) * P.npx)[q] = word;
+}
+__global__ __launch_bounds__(256) void k_remap_won_lab(MapsParams P, const uint4 *__restrict__ plist, const int *__restrict__ plist_count) {
+    const int lane = threadIdx.x & 63;
+    const int cand = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cand >= P.ncand) return;
+    Lab cl; cl.l = P.cand_lab[3 * cand]; cl.a = P.cand_lab[3 * cand + 1]; cl.b = P.cand_lab[3 * cand + 2];
+    uint8_t *map = P.maps + (size_t)cand * P.npx;
+    const int n = *plist_count;
+    for (int i = lane; i < n; i += 64) {
+        const uint4 e = plist[i];
+        const uint32_t thr = e.z;
+        bool win = thr == 0xffffffffu;
+        if (!win) {
+            Lab t; t.l = P.labpx[3 * (size_t)e.x]; t.a = P.labpx[3 * (size_t)e.x + 1]; t.b = P.labpx[3 * (size_t)e.x + 2];
+            const float d = ciede2000(cl, t), bd = __uint_as_float(thr & 0x7fffffffu);
+            win = (d < bd) || ((thr & 0x80000000u) && d == bd); // strict <, ties to the lower index (lib.rs:788-791)
+        }
+        if (win) map[e.x] = (uint8_t)P.si;
+    }
+}
+
 // ---- kernel entry points of the bodies above ----
 __global__ __launch_bounds__(1024) void k_sparse_scan(SparseParams P) { sparse_scan_body(P); }
 __global__ __launch_bounds__(256) void k_sparse_down(SparseParams P, int only_scale) { sparse_down_body(P, only_scale); }
