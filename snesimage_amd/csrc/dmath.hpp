@@ -17,8 +17,14 @@ SNES_HD uint32_t f32_bits(float f) { union { float f; uint32_t u; } v; v.f = f; 
 SNES_HD float f32_from_bits(uint32_t u) { union { float f; uint32_t u; } v; v.u = u; return v.f; }
 SNES_HD bool f64_signbit(double d) { union { double d; uint64_t u; } v; v.d = d; return (v.u >> 63) != 0; }
 
-// cube root: bit-hack seed, two Newton steps in binary64 (the musl / yuvxyb-math cbrtf).
-SNES_HD float d_cbrtf(float x) {
+// cube root: the musl / yuvxyb-math cbrtf — bit-hack seed, two Halley steps in binary64 (each with a division), the
+// binary64 result rounded to float.  That binary64 value t is within 6.3e-15 (2^-47) of the true root, so ANY binary64
+// approximation t' within 5e-16 rounds to the same float unless t' lies within ~7e-15 (relative) of a float rounding
+// boundary.  d_cbrtf computes such a t' without divisions — x^(-1/3) by three cubically convergent steps
+// y <- y + y*e*(1/3 + 2e/9), e = 1 - x*y^3, then x*y*y — and accepts it when both ends of a +-3e-14 band round to the
+// same float (all but ~5e-7 of the arguments); otherwise it runs the reference sequence itself.  Same floats, a third
+// of the cost: two binary64 divisions were most of linear_to_positive_xyb.
+SNES_HD float d_cbrtf_ref(float x) {
     uint32_t ui = f32_bits(x);
     uint32_t hx = ui & 0x7fffffffu;
     if (hx == 0u) return x;
@@ -30,6 +36,21 @@ SNES_HD float d_cbrtf(float x) {
     r = t * t * t;
     t = t * (xd + xd + r) / (xd + r + r);
     return (float)t;
+}
+SNES_HD float d_cbrtf(float x) {
+    const uint32_t ui = f32_bits(x), hx = ui & 0x7fffffffu;
+    if (hx - 0x00800000u >= 0x7f000000u) return d_cbrtf_ref(x); // zero, subnormal, inf, nan: not the fast path's business
+    const double ax = (double)f32_from_bits(hx);
+    double y = (double)f32_from_bits(0x54a21d2au - hx / 3u); // |x|^(-1/3) to ~3.5 %
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const double e = fma(-(ax * y), y * y, 1.0);
+        y = fma(y * e, fma(e, 2.0 / 9.0, 1.0 / 3.0), y);
+    }
+    const double t = (ax * y) * y;
+    const float lo = (float)(t * (1.0 - 3e-14)), hi = (float)(t * (1.0 + 3e-14));
+    if (lo != hi) return d_cbrtf_ref(x);
+    return f32_from_bits((ui & 0x80000000u) | f32_bits(lo));
 }
 
 // exp(x), x <= 0.

@@ -54,6 +54,25 @@ def test_device_math_bit_exact(S, O):
     assert np.array_equal(S.debug_math(4, xa, ya), O.det_math(4, xa, ya))
 
 
+def test_device_cbrt_equals_reference_sequence(S, O):
+    """The device cube root (division-free evaluation + rounding-boundary guard, dmath.hpp) returns the float of the
+    restated musl sequence for every argument: wide random sweep, signs, specials, and arguments whose root sits as
+    close to a float rounding boundary as single precision allows (cubes of half-way points)."""
+    rng = np.random.default_rng(13)
+    parts = [np.exp(rng.uniform(np.log(1e-37), np.log(3e38), 1_500_000)), rng.uniform(0, 4, 1_500_000), rng.uniform(1, 8, 500_000),
+             -rng.uniform(0, 50, 100_000)]
+    f = rng.uniform(0.5, 2.0, 400_000).astype(np.float32)
+    mid = f.astype(np.float64) + 0.5 * np.spacing(f).astype(np.float64)   # exactly between two floats
+    for bump in (0.0, 1.0, -1.0, 2.0, -2.0):                                # the nearest few floats to mid^3
+        c = (mid ** 3).astype(np.float32)
+        parts.append(np.nextafter(c, np.float32(np.inf) if bump > 0 else -np.float32(np.inf)) if abs(bump) == 1.0 else
+                     (np.nextafter(np.nextafter(c, np.float32(np.inf * np.sign(bump))), np.float32(np.inf * np.sign(bump))) if bump else c))
+    parts.append(np.array([0.0, -0.0, 1e-45, 1e-39, -1e-40, 1.0, 8.0, 27.0, 3.4e38, np.inf, -np.inf], np.float64))
+    x = np.concatenate([np.asarray(p, np.float64) for p in parts]).astype(np.float32)
+    got, want = S.debug_math(3, x), O.det_math(3, x)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_device_lab_and_ciede_bit_exact(S, O):
     rng = np.random.default_rng(12)
     rgb = rng.integers(0, 256, size=(4000, 3)).astype(np.uint8)
