@@ -310,7 +310,7 @@ int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double
         Dp.W = (int)c->W; Dp.H = (int)c->H; Dp.sub_size = (int)c->sub_size; Dp.ncol = c->ncol; Dp.slot_ci = slot_ci; Dp.perceptual = c->perceptual ? 1 : 0;
         launch_dither(c, Dp, nc);
         // the transposed copy only feeds the generic scale-0 H pass
-        hipLaunchKernelGGL(k_maps_relayout, dim3((unsigned)((c->npx / 4 + 255) / 256), nc), dim3(256), 0, c->stream, c->d_maps, (int)c->W, (int)c->H,
+        hipLaunchKernelGGL(k_maps_relayout, dim3((unsigned)(c->H / 4), nc), dim3(256), 0, c->stream, c->d_maps, (int)c->W, (int)c->H,
                            reinterpret_cast<uint32_t *>(c->d_mapsR4), (c->fast_mask & 1) ? (uint32_t *)nullptr : reinterpret_cast<uint32_t *>(c->d_mapsT));
         if (d_maps_out) HIPCHK(hipMemcpyAsync(d_maps_out, c->d_maps, c->npx * (size_t)nc, hipMemcpyDeviceToDevice, c->stream));
     } else if (d_maps_out) {

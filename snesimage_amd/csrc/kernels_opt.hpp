@@ -260,14 +260,17 @@ __global__ __launch_bounds__(1024) void k_take_best_map(const StepResult *__rest
 // Row-blocked (R4: [y/4][x][y%4]) and, on request, transposed ([x][y]) copies of the row-major per-candidate maps.
 // Both hold the same word — rows 4q..4q+3 of column x — at different places.
 __global__ __launch_bounds__(256) void k_maps_relayout(const uint8_t *__restrict__ maps, int W, int H, uint32_t *__restrict__ r4, uint32_t *__restrict__ mT) {
-    const int i = blockIdx.x * 256 + threadIdx.x; // (q, x)
-    if (i >= W * (H >> 2)) return;
+    // block = one group of four rows (W = 256): thread t fetches the word of columns 4(t%64).. of row t/64, LDS turns the
+    // 4x256 bytes around, thread t stores the word of column t (rows 4q..4q+3)
+    __shared__ uint8_t s_b[4][256 + 4];
+    const int q = blockIdx.x, t = threadIdx.x;
     const size_t cb = (size_t)blockIdx.y * W * H;
-    const int q = i / W, x = i - q * W;
-    const uint8_t *m = maps + cb + (size_t)(4 * q) * W + x;
-    const uint32_t w = (uint32_t)m[0] | ((uint32_t)m[W] << 8) | ((uint32_t)m[2 * W] << 16) | ((uint32_t)m[3 * W] << 24);
-    r4[(cb >> 2) + i] = w;
-    if (mT) mT[(cb >> 2) + (size_t)x * (H >> 2) + q] = w;
+    const uint32_t w4 = reinterpret_cast<const uint32_t *>(maps + cb + (size_t)(4 * q + (t >> 6)) * W)[t & 63];
+    *reinterpret_cast<uint32_t *>(&s_b[t >> 6][4 * (t & 63)]) = w4;
+    __syncthreads();
+    const uint32_t w = (uint32_t)s_b[0][t] | ((uint32_t)s_b[1][t] << 8) | ((uint32_t)s_b[2][t] << 16) | ((uint32_t)s_b[3][t] << 24);
+    r4[(cb >> 2) + (size_t)q * W + t] = w;
+    if (mT) mT[(cb >> 2) + (size_t)t * (H >> 2) + q] = w;
 }
 
 // ---- optimizer step: candidates and commit -------------------------------------------------------
