@@ -73,8 +73,8 @@ def bench_images(args, torch, dist, S, world, rank, local_rank, device, force_di
     sub_count, sub_size = 8, 15
     mine = shard_images(args.images * world, rank, world)
     batch = ImageBatch.synthetic(mine, sub_count, sub_size, device=local_rank, candidates=args.batch, host_threads=args.host_threads,
-                                 batched=not args.per_image_launches, groups=args.groups)
-    batch.initialize()  # untimed: TileAssignment + Clustering of every image
+                                 batched=not args.per_image_launches, groups=args.groups, perceptual=args.perceptual)
+    batch.initialize(drop_failed=True)  # untimed: TileAssignment + Clustering of every image
     batch.run(args.warmup)
     torch.cuda.synchronize()
     if world > 1:
@@ -92,16 +92,17 @@ def bench_images(args, torch, dist, S, world, rank, local_rank, device, force_di
         dt = float(t.item())
     errs = batch.errors()
     if rank == 0:
-        total = len(mine) * world * args.batch * args.steps
+        total = len(batch) * world * args.batch * args.steps  # (ranks hold equal blocks; an image dropped at initialisation is not counted)
         value = total / dt
         out = {
             "metric": "candidate palettes scored/sec", "value": value, "unit": "candidates/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "throughput mode: %d synthetic 256x256 RGBA8 images per GPU (seeds 0x5EED0000+i), 8 subpalettes x 15, "
-                                   "RGB redmean distance, no dither, %d candidates per optimizer call per image, one call on every "
-                                   "image per step, remap + SSIMULACRA2 per candidate, no collective" % (len(mine), args.batch),
-                       "images_per_gpu": len(mine), "batch": args.batch, "config": "images", "host_threads": args.host_threads,
+                                   "%s, no dither, %d candidates per optimizer call per image, one call on every "
+                                   "image per step, remap + SSIMULACRA2 per candidate, no collective" % (
+                                       len(mine), "CIEDE2000 (--perceptual-palettes)" if args.perceptual else "RGB redmean distance", args.batch),
+                       "images_per_gpu": len(batch), "dropped_at_init": batch.dropped, "batch": args.batch, "config": "images", "host_threads": args.host_threads,
                        "launches": "per image" if args.per_image_launches else "one per stage for all images",
                        "mean_final_error": sum(errs) / len(errs)},
             "roofline": {"bound": "hbm", "kernel": "pipeline (kernels of different images overlap; no per-kernel timing in this mode)",
@@ -126,6 +127,7 @@ def main():
                          "(lib.rs:205) for --config images")
     ap.add_argument("--images", type=int, default=128, help="--config images: images per GPU (1,024 over 8 GPUs)")
     ap.add_argument("--host-threads", type=int, default=8, help="--config images: host threads enqueueing optimizer calls")
+    ap.add_argument("--perceptual", action="store_true", help="--config images: CIEDE2000 distance (--perceptual-palettes)")
     ap.add_argument("--groups", type=int, default=4, help="--config images: batches stepped side by side on their own streams")
     ap.add_argument("--per-image-launches", action="store_true",
                     help="--config images: one stream and one set of launches per image instead of one launch per stage for all images")

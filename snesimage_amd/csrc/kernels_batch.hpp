@@ -13,6 +13,7 @@ struct BatchArgs {
     unsigned long long key; const uint8_t *colors_in; uint8_t *colors; uint8_t *cand; const float *eotf; float *cand_tab;
     const double *part; double *errors; double *inc_err; StepResult *last; PaletteTables T;
     int method, n, slot, channel, nes, npx;
+    const float *lab_eotf; float *cand_lab; // --perceptual-palettes
 };
 
 #define SNES_BATCH_IMG const BatchArgs &a = A[blockIdx.z]
@@ -26,6 +27,13 @@ __global__ __launch_bounds__(1024) void kb_sparse_scan(const BatchArgs *__restri
 __global__ __launch_bounds__(256) void kb_base_down(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; base_down_body(a.Pb); }
 __global__ __launch_bounds__(256) void kb_sparse_down(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; sparse_down_body(a.Pc, 0); }
 __global__ void kb_candidate_tables(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; candidate_tables_body(a.cand, a.n, a.eotf, a.cand_tab); }
+__global__ void kb_candidate_lab(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; candidate_lab_body(a.cand_tab, a.n, a.lab_eotf, a.cand_lab); }
+__global__ __launch_bounds__(256) void kb_clear_bitmaps(const BatchArgs *__restrict__ A) { // the won-pixel bitmaps of the call's candidates (npx/32 words each)
+    SNES_BATCH_IMG;
+    const size_t words = (size_t)a.n * (a.npx / 32);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) a.Pc.bitmap[i] = 0u;
+}
+__global__ __launch_bounds__(256) void kb_sparse_scan_lab(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; sparse_scan_lab_body(a.Pc); }
 __global__ __launch_bounds__(64) void kb_sparse_h(const BatchArgs *__restrict__ A, int base) { SNES_BATCH_IMG; sparse_h_body(base ? a.Pb : a.Pc); }
 __global__ __launch_bounds__(256, 1) void kb_sparse_v_base(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; sparse_v_base_body(a.Pb); }
 __global__ __launch_bounds__(256, 4) void kb_sparse_v(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; sparse_v_body<false, 2, 2>(a.Pc, (int)blockIdx.y); }

@@ -14,13 +14,14 @@ __global__ void k_palette_lab(const uint32_t *__restrict__ pal_rgb8, int ncol, c
     Lab l = linear_to_lab(lab_eotf[c & 0xff], lab_eotf[(c >> 8) & 0xff], lab_eotf[(c >> 16) & 0xff]);
     pal_lab[3 * i] = l.l; pal_lab[3 * i + 1] = l.a; pal_lab[3 * i + 2] = l.b;
 }
-__global__ void k_candidate_lab(const float *__restrict__ cand_tab, int n, const float *__restrict__ lab_eotf, float *__restrict__ cand_lab) {
+__device__ __forceinline__ void candidate_lab_body(const float *__restrict__ cand_tab, int n, const float *__restrict__ lab_eotf, float *__restrict__ cand_lab) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     uint32_t c = __float_as_uint(cand_tab[8 * (size_t)k + 6]);
     Lab l = linear_to_lab(lab_eotf[c & 0xff], lab_eotf[(c >> 8) & 0xff], lab_eotf[(c >> 16) & 0xff]);
     cand_lab[3 * k] = l.l; cand_lab[3 * k + 1] = l.a; cand_lab[3 * k + 2] = l.b;
 }
+__global__ void k_candidate_lab(const float *__restrict__ cand_tab, int n, const float *__restrict__ lab_eotf, float *__restrict__ cand_lab) { candidate_lab_body(cand_tab, n, lab_eotf, cand_lab); }
 __global__ void k_candidate_slot(float *__restrict__ cand_tab, int n, uint32_t slot_ci) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) cand_tab[8 * (size_t)k + 7] = __uint_as_float(slot_ci);

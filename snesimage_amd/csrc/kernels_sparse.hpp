@@ -71,7 +71,7 @@ __device__ __forceinline__ unsigned long long pair_or_compress(unsigned long lon
 __device__ __forceinline__ uint32_t won_bit(const uint32_t *bm, int px) { return (bm[px >> 5] >> (px & 31)) & 1u; }
 
 // ---- perceptual scan: CIEDE2000 win test per contested pixel, one wave per candidate ------------------------
-__global__ __launch_bounds__(256) void k_sparse_scan_lab(SparseParams P) {
+__device__ __forceinline__ void sparse_scan_lab_body(const SparseParams &P) {
     const Geom &G = P.G;
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
@@ -824,6 +824,7 @@ __global__ __launch_bounds__(256) void k_remap_won_lab(MapsParams P, const uint4
 }
 
 // ---- kernel entry points of the bodies above ----
+__global__ __launch_bounds__(256) void k_sparse_scan_lab(SparseParams P) { sparse_scan_lab_body(P); }
 __global__ __launch_bounds__(1024) void k_sparse_scan(SparseParams P) { sparse_scan_body(P); }
 __global__ __launch_bounds__(256) void k_sparse_down(SparseParams P, int only_scale) { sparse_down_body(P, only_scale); }
 __global__ __launch_bounds__(256) void k_base_down(SparseParams P) { base_down_body(P); }

@@ -42,6 +42,7 @@ class ImageBatch:
             self.images.append(img)
         self.host_threads = max(1, min(int(host_threads), len(self.images)))
         self.calls_done = 0
+        self.dropped = []
 
     @classmethod
     def synthetic(cls, indices, sub_count, sub_size, **kw):
@@ -68,13 +69,26 @@ class ImageBatch:
         if errs:
             raise errs[0]
 
-    def initialize(self):
-        """The reference's TileAssignment and Clustering phases for every image (lib.rs:982-1000)."""
+    def initialize(self, drop_failed=False):
+        """The reference's TileAssignment and Clustering phases for every image (lib.rs:982-1000).  `drop_failed`: an image
+        on which cogset's k-means precondition fails (the reference panics there) leaves the batch instead of
+        ending it; `self.dropped` lists the indices."""
+        failed = []
+
         def init(mine):
             for i in mine:
-                self.images[i].initialize_tiles()
-                self.images[i].recalculate_palettes()
+                try:
+                    self.images[i].initialize_tiles()
+                    self.images[i].recalculate_palettes()
+                except api.SnesImageError as e:
+                    if not (drop_failed and e.code == -4):
+                        raise
+                    failed.append(i)
         self._parallel(init)
+        self.dropped = [self.ids[i] for i in sorted(failed)]
+        for i in sorted(failed, reverse=True):
+            self.images[i].close()
+            del self.images[i], self.ids[i]
         if self.batched:
             self._open_batch()
 

@@ -17,8 +17,8 @@ def test_shard_images_is_a_partition(n, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("batched", [False, True])
-def test_concurrent_images_equal_one_at_a_time(batched):
+@pytest.mark.parametrize("batched,flags", [(False, {}), (True, {}), (True, {"perceptual": True})])
+def test_concurrent_images_equal_one_at_a_time(batched, flags):
     """Optimizer calls of several images — enqueued side by side from several host threads, or issued as one launch per
     stage for all of them — give, for every image, exactly the state that stepping that image alone gives."""
     import snesimage_amd as S
@@ -26,13 +26,13 @@ def test_concurrent_images_equal_one_at_a_time(batched):
     from snesimage_amd.throughput import IMAGE_SEED0, ImageBatch
 
     ids = [5, 6, 7, 900]
-    batch = ImageBatch.synthetic(ids, 4, 7, candidates=24, host_threads=3, batched=batched)
+    batch = ImageBatch.synthetic(ids, 4, 7, candidates=24, host_threads=3, batched=batched, **flags)
     batch.initialize()
     batch.run(3)
     batch.run(4)  # the schedule continues where the first run stopped
     sched = S.schedule(4, 7, 7)
     for pos, gid in enumerate(ids):
-        solo = S.OptimizedImage(synth_image(IMAGE_SEED0 + gid), 4, 7)
+        solo = S.OptimizedImage(synth_image(IMAGE_SEED0 + gid), 4, 7, **flags)
         solo.initialize_tiles()
         solo.recalculate_palettes()
         for j, (method, p, idx, ch, _) in enumerate(sched):
@@ -49,7 +49,7 @@ def test_concurrent_images_equal_one_at_a_time(batched):
 def test_batch_rejects_what_it_does_not_cover():
     import snesimage_amd as S
     from snesimage_amd.throughput import ImageBatch
-    for flags in ({"dither": True}, {"perceptual": True}):
+    for flags in ({"dither": True}, {"dither": True, "perceptual": True}):
         b = ImageBatch.synthetic([1, 2], 2, 3, candidates=8, batched=True, **flags)
         with pytest.raises(S.SnesImageError) as e:
             b.initialize()
