@@ -6,7 +6,8 @@
 // --calls optimizer calls in the reference's slot order (src/lib.rs:881-933) -> write the JSON.
 // Extra flags exist only because the reference is interactive and unseeded: --seed, --calls,
 // --candidates, --device, --tile-palettes FILE (1024 bytes, replaces the mouse clicks of
-// src/lib.rs:1005-1017), --preview FILE.png (source | result side by side, the picture the SDL window of
+// src/lib.rs:1005-1017), --resume FILE.json (start from a previous output instead of the k-means initialisers: the
+// reference's TODO.md:38-39), --preview FILE.png (source | result side by side, the picture the SDL window of
 // src/lib.rs:937-960 shows).  The source image is a PNG (png_io.hpp restates `image::open(..).into_rgba8()`,
 // src/lib.rs:836, for that format), a raw RGBA8 file of 256*H*4 bytes, or `synth:SEED`.
 // The host language the north star asks for is Rust; no Rust toolchain exists in this image, so the
@@ -55,9 +56,33 @@ void usage() {
             "  -d, --dither\n      --perceptual-palettes\n      --nes\n"
             "      --calls <N>          optimizer calls to run [default: 0]\n      --candidates <N>     random candidates per call [default: 64]\n"
             "      --seed <N>           candidate RNG seed [default: 1]\n      --device <N>         HIP device [default: 0]\n"
-            "      --tile-palettes <F>  1024-byte tile->subpalette override\n      --preview <F>        write source | result as a PNG\n"
+            "      --tile-palettes <F>  1024-byte tile->subpalette override\n      --resume <F>         start from the palette and tile palettes of a previous JSON output\n"
+            "      --preview <F>        write source | result as a PNG\n"
             "      --decode-only        write the decoded source as raw RGBA8 to <TARGET_FILENAME> and stop (no GPU)\n  -h, --help\n  -V, --version\n");
 }
+// the flat integer array stored under `"key":[...]` in one of this driver's (or the reference's) JSON outputs
+bool json_int_array(const std::string &path, const char *key, std::vector<long> &out) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::string text; char buf[65536]; size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
+    fclose(f);
+    const std::string pat = std::string("\"") + key + "\"";
+    size_t at = text.find(pat);
+    if (at == std::string::npos) return false;
+    at = text.find('[', at + pat.size());
+    if (at == std::string::npos) return false;
+    out.clear();
+    for (size_t i = at + 1; i < text.size(); ) {
+        const char ch = text[i];
+        if (ch == ']') return true;
+        if (ch == '-' || (ch >= '0' && ch <= '9')) { char *end = nullptr; out.push_back(strtol(text.c_str() + i, &end, 10)); i = (size_t)(end - text.c_str()); }
+        else if (ch == ',' || ch == ' ' || ch == '\n' || ch == '\r' || ch == '\t') i++;
+        else return false; // nested arrays or anything else: not a flat integer array
+    }
+    return false;
+}
+
 void synth(uint64_t seed, uint32_t w, uint32_t h, std::vector<uint8_t> &out) {
     out.resize((size_t)w * h * 4);
     uint64_t s = seed;
@@ -79,7 +104,7 @@ int main(int argc, char **argv) {
     uint32_t count = 1, size = 7, flags = 0, calls = 0, ncand = 64; // src/config.rs:13-18 defaults
     uint64_t seed = 1;
     int device = 0;
-    std::string tile_file, preview_file;
+    std::string tile_file, preview_file, resume_file;
     bool decode_only = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -95,6 +120,7 @@ int main(int argc, char **argv) {
         else if (a == "--device") device = atoi(need("--device"));
         else if (a == "--tile-palettes") tile_file = need("--tile-palettes");
         else if (a == "--preview") preview_file = need("--preview");
+        else if (a == "--resume") resume_file = need("--resume");
         else if (a == "--decode-only") decode_only = true;
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else if (a == "-V" || a == "--version") { printf("snesimage 0.1.1 (%s)\n", snesimage_version()); return 0; }
@@ -137,17 +163,34 @@ int main(int argc, char **argv) {
     }
     snesimage_ctx *ctx = nullptr;
     if (snesimage_create(rgba.data(), w, h, count, size, flags, device, &ctx) != 0) die(snesimage_last_error());
-    if (snesimage_initialize_tiles(ctx) != 0) die(std::string("Unable to initialize tiles: ") + snesimage_last_error()); // src/lib.rs:851-853
-    log_info("Finished assigning initial tiles");
-    if (!tile_file.empty()) {
-        std::vector<uint8_t> tp(1024);
-        FILE *f = fopen(tile_file.c_str(), "rb");
-        if (!f || fread(tp.data(), 1, 1024, f) != 1024) die("cannot read 1024 bytes from " + tile_file);
-        fclose(f);
-        if (snesimage_set_tile_palettes(ctx, tp.data()) != 0) die(snesimage_last_error());
+    if (!resume_file.empty()) { // palette + tile_palettes of an earlier output (src/lib.rs:579-625); the tiles follow from optimize()
+        std::vector<long> pal, tp;
+        if (!json_int_array(resume_file, "palette", pal) || !json_int_array(resume_file, "tile_palettes", tp)) die("cannot read palette and tile_palettes from " + resume_file);
+        if (pal.size() != 16 * (size_t)count || tp.size() != 1024) die("resume file does not match --subpalette-count (palette must hold 16 entries per subpalette, tile_palettes 1024)");
+        std::vector<uint8_t> tp8(1024), rgb5(3 * (size_t)count * size);
+        for (size_t i = 0; i < 1024; i++) { if (tp[i] < 0 || tp[i] >= (long)count) die("resume file: tile palette out of range"); tp8[i] = (uint8_t)tp[i]; }
+        for (uint32_t p = 0; p < count; p++)
+            for (uint32_t i = 0; i < size; i++) { // slot 0 of every 16 is the transparent colour (src/lib.rs:583-585)
+                const long v = pal[16 * (size_t)p + 1 + i];
+                if (v < 0 || v > 0x7fff) die("resume file: colour out of range");
+                uint8_t *o = &rgb5[3 * ((size_t)p * size + i)];
+                o[0] = (uint8_t)(v & 31); o[1] = (uint8_t)((v >> 5) & 31); o[2] = (uint8_t)((v >> 10) & 31);
+            }
+        if (snesimage_set_tile_palettes(ctx, tp8.data()) != 0 || snesimage_set_palette_rgb5(ctx, rgb5.data()) != 0 || snesimage_optimize(ctx) != 0) die(snesimage_last_error());
+        log_info("Resumed from " + resume_file);
+    } else {
+        if (snesimage_initialize_tiles(ctx) != 0) die(std::string("Unable to initialize tiles: ") + snesimage_last_error()); // src/lib.rs:851-853
+        log_info("Finished assigning initial tiles");
+        if (!tile_file.empty()) {
+            std::vector<uint8_t> tp(1024);
+            FILE *f = fopen(tile_file.c_str(), "rb");
+            if (!f || fread(tp.data(), 1, 1024, f) != 1024) die("cannot read 1024 bytes from " + tile_file);
+            fclose(f);
+            if (snesimage_set_tile_palettes(ctx, tp.data()) != 0) die(snesimage_last_error());
+        }
+        log_info("Generating initial palettes"); // src/lib.rs:985-989
+        if (snesimage_recalculate_palettes(ctx) != 0) die(std::string("Unable to recalculate palettes: ") + snesimage_last_error());
     }
-    log_info("Generating initial palettes"); // src/lib.rs:985-989
-    if (snesimage_recalculate_palettes(ctx) != 0) die(std::string("Unable to recalculate palettes: ") + snesimage_last_error());
     log_info("Beginning optimization"); // src/lib.rs:992
     uint32_t palette = 0, index = 0, channel = 0, step = 0;
     double last_error = 1.7976931348623157e308;

@@ -126,3 +126,22 @@ def test_cli_png_source_and_preview(tmp_path):
         blk[v == 0] = 0
         want[ty * 8:ty * 8 + 8, tx * 8:tx * 8 + 8] = blk
     assert np.array_equal(both[:, 256:], want)
+
+
+@pytest.mark.gpu
+def test_cli_resume_continues_from_a_previous_output(tmp_path):
+    """--resume: palette and tile palettes come from an earlier JSON, the tiles from optimize() on them — so resuming with
+    no further calls reproduces the file, and a bad file is an error in the reference's convention."""
+    a, b, c = tmp_path / "a.json", tmp_path / "b.json", tmp_path / "c.json"
+    base = ["synth:1592590339", "-c", "4", "-s", "7"]
+    assert run(*base[:1], str(a), *base[1:], "--calls", "6", "--candidates", "12").returncode == 0
+    r = run(*base[:1], str(b), *base[1:], "--resume", str(a))
+    assert r.returncode == 0 and "Resumed from" in r.stdout and "Finished assigning initial tiles" not in r.stdout
+    assert b.read_text() == a.read_text()
+    r = run(*base[:1], str(c), *base[1:], "--resume", str(a), "--calls", "4", "--candidates", "12")
+    assert r.returncode == 0 and json.loads(c.read_text())["tile_palettes"] == json.loads(a.read_text())["tile_palettes"]
+    r = run(*base[:1], str(c), "-c", "2", "-s", "7", "--resume", str(a))  # 4 subpalettes in the file, 2 asked for
+    assert r.returncode == 1 and "Error running application:" in r.stdout
+    (tmp_path / "junk.json").write_text('{"palette":[[1,2]],"tile_palettes":[]}')
+    r = run(*base[:1], str(c), *base[1:], "--resume", str(tmp_path / "junk.json"))
+    assert r.returncode == 1 and "Error running application:" in r.stdout
