@@ -61,6 +61,7 @@ struct SparseParams {
     float *store; CandMeta *meta;
     unsigned int *items; int *item_count; long long item_stride; // per scale: items[s*item_stride + i] = cand*256 + slot*4 + ch
     float *ckf; double *cka; double *part;
+    const int *order; // k_sparse_v: candidates of the launch, longest column sweeps first (k_sparse_order); nullptr = as listed
 };
 
 __device__ __forceinline__ uint32_t sparse_ci(uint32_t lo, uint32_t thr, uint32_t crgb, uint32_t ncol) {
@@ -537,7 +538,7 @@ __device__ __forceinline__ void sparse_v_body(const SparseParams &P, const int s
     const int pair_raw = blockIdx.x * ppw + ql;
     const bool active = pair_raw < npairs;
     const int pair = active ? pair_raw : 0;
-    const int k = is_base ? P.base : P.k0 + pair / 3, ch = pair % 3;
+    const int k = is_base ? P.base : P.k0 + (P.order ? P.order[pair / 3] : pair / 3), ch = pair % 3;
     if (S0) { // W = 256: the block is one (candidate, channel) pair, so one channel of the XYB table is enough
         s_lut[t] = (t < P.ncol + 2) ? P.pal_xyb[3 * t + ch] : 0.0f;
     }
@@ -547,7 +548,8 @@ __device__ __forceinline__ void sparse_v_body(const SparseParams &P, const int s
     // group -> slot table of this block's pairs, staged in LDS so the per-group pointer choice costs no global load
     for (int i = t; i < ppw * H4; i += 256) {
         const int pr = blockIdx.x * ppw + i / H4;
-        const int kk = is_base ? P.base : P.k0 + (pr < npairs ? pr : 0) / 3;
+        const int pq = (pr < npairs ? pr : 0) / 3;
+        const int kk = is_base ? P.base : P.k0 + (P.order ? P.order[pq] : pq);
         s_gslot[i] = (P.meta + kk)->gslot[P.S.goff[s] + i % H4];
     }
     __syncthreads();
@@ -822,6 +824,28 @@ __global__ __launch_bounds__(256) void k_remap_won_lab(MapsParams P, const uint4
         if (win) map[e.x] = (uint8_t)P.si;
     }
 }
+
+// Longest first: the V pass of a candidate sweeps every column from its first changed group to the bottom, so blocks
+// differ several-fold in length; handing them out in descending length keeps the tail of the launch short.
+// Counting sort by the first changed group of scale 0 (H/4 + 1 bins), one block per launch.
+__device__ __forceinline__ void sparse_order_body(const SparseParams &P, int *__restrict__ order) {
+    __shared__ int s_cnt[66];
+    const int t = threadIdx.x, H4 = P.G.sh[0] >> 2;
+    if (t < 66) s_cnt[t] = 0;
+    __syncthreads();
+    for (int i = t; i < P.ncand; i += blockDim.x) {
+        const CandMeta *M = P.meta + P.k0 + i;
+        atomicAdd(&s_cnt[M->ngroups[0] ? (int)M->glist[P.S.goff[0]] : H4], 1);
+    }
+    __syncthreads();
+    if (t == 0) { int run = 0; for (int b = 0; b <= H4; b++) { const int c = s_cnt[b]; s_cnt[b] = run; run += c; } }
+    __syncthreads();
+    for (int i = t; i < P.ncand; i += blockDim.x) { // the order inside a bin is arbitrary: results do not depend on it
+        const CandMeta *M = P.meta + P.k0 + i;
+        order[atomicAdd(&s_cnt[M->ngroups[0] ? (int)M->glist[P.S.goff[0]] : H4], 1)] = i;
+    }
+}
+__global__ __launch_bounds__(256) void k_sparse_order(SparseParams P, int *__restrict__ order) { sparse_order_body(P, order); }
 
 // ---- kernel entry points of the bodies above ----
 __global__ __launch_bounds__(256) void k_sparse_scan_lab(SparseParams P) { sparse_scan_lab_body(P); }
