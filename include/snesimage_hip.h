@@ -52,7 +52,8 @@ void snesimage_destroy(snesimage_ctx *ctx);
 int32_t snesimage_set_stream(snesimage_ctx *ctx, void *hip_stream);
 /* Block until all work queued by this context has finished. */
 int32_t snesimage_sync(snesimage_ctx *ctx);
-/* Candidates scored per internal launch group (bounds the workspace); default 1024. */
+/* Most candidates one internal launch group takes (bounds the workspace, which grows on demand);
+ * default 4096.  A candidate list is split evenly over the context's launch lanes up to this bound. */
 int32_t snesimage_set_chunk(snesimage_ctx *ctx, uint32_t chunk);
 
 int32_t snesimage_initialize_tiles(snesimage_ctx *ctx);     /* lib.rs:79-189  */

@@ -98,7 +98,7 @@ struct snesimage_ctx {
     Geom G{};
     BlurK K{};
     size_t npx = 0, src_floats = 0;
-    uint32_t chunk = 1024, chunk_alloc = 0;
+    uint32_t chunk = 4096, chunk_alloc = 0; // chunk: most candidates one launch group takes (a list is split evenly over the lanes up to that); chunk_alloc: dense workspace per lane
 
     std::vector<uint8_t> h_orig; float h_eotf[256], h_lab_eotf[256];
 
@@ -179,8 +179,10 @@ int32_t alloc_lane(snesimage_ctx *c, uint32_t chunk, float *&d_work, float *&d_c
     }
     return SNES_OK;
 }
+// grow-only: `chunk` = candidates per lane the dense kernels are about to handle
 int32_t alloc_workspace(snesimage_ctx *c, uint32_t chunk) {
     if (c->chunk_alloc >= chunk && c->extra.size() + 1 >= c->nlanes) return SNES_OK;
+    if (chunk < c->chunk_alloc) chunk = c->chunk_alloc;
     HIPCHK(hipStreamSynchronize(c->stream));
     for (auto &L : c->extra) HIPCHK(hipStreamSynchronize(L.stream));
     CHECK(alloc_lane(c, chunk, c->d_work, c->d_cand_tab, c->d_cand_lab, c->d_part, c->d_maps, c->d_mapsT, c->d_mapsC4, c->d_mapsR4));
@@ -229,7 +231,7 @@ int32_t ensure_tables(snesimage_ctx *c) {
 // Source-side pyramid: img1, img1T, mu1, s11 at every scale (depends only on `original`).
 int32_t ensure_source(snesimage_ctx *c) {
     if (c->src_valid) return SNES_OK;
-    CHECK(alloc_workspace(c, c->chunk));
+    CHECK(alloc_workspace(c, 1));
     const Geom &G = c->G;
     hipLaunchKernelGGL(k_source_scale0, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, c->d_orig, c->d_eotf, (int)c->W, (int)c->H, c->d_lin0,
                        c->d_img1, c->d_img1T);
@@ -382,9 +384,10 @@ int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double
 }
 
 // ---- row-sparse path ------------------------------------------------------------------------------------
-int32_t sparse_alloc(snesimage_ctx *c) {
+// grow-only: `need` = candidates per lane of the launch groups to come
+int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
     auto &sp = c->sp;
-    if (sp.cap >= c->chunk) return SNES_OK;
+    if (sp.cap >= need) return SNES_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
     dfree(sp.store); dfree(sp.cand_tab); dfree(sp.ckf); dfree(sp.cka); dfree(sp.part); dfree(sp.meta); dfree(sp.items); dfree(sp.item_count); dfree(sp.plist); sp.plist_count = nullptr;
     const Geom &G = c->G;
@@ -401,8 +404,8 @@ int32_t sparse_alloc(snesimage_ctx *c) {
         S.goff[s] = go; go += G.sh[s] / 4;
     }
     S.cand_stride = off;
-    const size_t ncap = (size_t)c->nlanes * c->chunk + 1; // + the base image B
-    sp.item_stride = (long long)c->chunk * (G.sh[0] / 4) * 3;
+    const size_t ncap = (size_t)c->nlanes * need + 1; // + the base image B
+    sp.item_stride = (long long)need * (G.sh[0] / 4) * 3;
     HIPCHK(hipMalloc(&sp.store, sizeof(float) * (size_t)S.cand_stride * ncap));
     HIPCHK(hipMalloc(&sp.cand_tab, sizeof(float) * 8 * ncap));
     if (c->perceptual) {
@@ -428,14 +431,14 @@ int32_t sparse_alloc(snesimage_ctx *c) {
     sp.plist_count = sp.item_count + (size_t)kMaxScales * (c->nlanes + 1);
     sp.counters_cleared = true;
     HIPCHK(hipMalloc(&sp.plist, sizeof(uint4) * c->npx));
-    sp.cap = c->chunk; sp.plist_valid = false;
+    sp.cap = need; sp.plist_valid = false;
     return SNES_OK;
 }
 
 SparseParams sparse_params(snesimage_ctx *c, uint32_t lane) {
     auto &sp = c->sp;
     SparseParams P{};
-    P.G = c->G; P.S = sp.S; P.K = c->K; P.ncol = c->ncol; P.base = (int)(c->nlanes * c->chunk);
+    P.G = c->G; P.S = sp.S; P.K = c->K; P.ncol = c->ncol; P.base = (int)(c->nlanes * sp.cap);
     P.pack = c->d_pack; P.packC4 = c->d_packC4; P.packR4 = c->d_packR4; P.plist = sp.plist; P.plist_count = sp.plist_count;
     P.pal_lin = c->d_pal_lin; P.pal_xyb = c->d_pal_xyb; P.cand_tab = sp.cand_tab;
     P.perceptual = c->perceptual ? 1 : 0; P.labpx = c->d_labpx; P.cand_lab = sp.cand_lab; P.bitmap = sp.bitmap;
@@ -477,7 +480,7 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     auto &sp = c->sp;
     const Geom &G = c->G;
     SparseParams P = sparse_params(c, lane);
-    P.is_base = 0; P.ncand = (int)nc; P.k0 = (int)(lane * c->chunk);
+    P.is_base = 0; P.ncand = (int)nc; P.k0 = (int)(lane * sp.cap);
     snesimage_ctx::TimingRec tr{}; tr.n = nc;
     if (c->timing) { for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&tr.ev[i])); HIPCHK(hipEventRecord(tr.ev[0], stream)); }
     hipLaunchKernelGGL(k_candidate_tables, dim3((nc + 63) / 64), dim3(64), 0, stream, d_rgb5, (int)nc, c->d_eotf, sp.cand_tab + 8 * (size_t)P.k0);
@@ -513,21 +516,25 @@ struct LaneScope {
 
 // errors of candidate j of the list go to d_errors[err_offset + j * err_stride]
 int32_t score_list(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t n, double *d_errors, int err_stride, int err_offset, int sp, int si, uint8_t *d_maps_out) {
-    CHECK(alloc_workspace(c, c->chunk));
+    // one launch group per lane when the list allows it (fewer, larger launches; the V pass sorts each group by length)
+    uint32_t chunk = (n + c->nlanes - 1) / c->nlanes;
+    if (chunk < 64) chunk = 64;
+    if (chunk > c->chunk) chunk = c->chunk;
+    const bool sparse = c->sp.enabled && !d_maps_out && sp >= 0 && n >= c->sp.min_n && c->pack_mode == 2;
+    CHECK(alloc_workspace(c, sparse ? 1 : chunk));
     CHECK(ensure_tables(c));
     CHECK(ensure_source(c));
-    const uint32_t nchunks = (n + c->chunk - 1) / c->chunk;
+    const uint32_t nchunks = (n + chunk - 1) / chunk;
     const uint32_t nl = nchunks < c->nlanes ? nchunks : c->nlanes;
-    const bool sparse = c->sp.enabled && !d_maps_out && sp >= 0 && n >= c->sp.min_n && c->pack_mode == 2;
-    if (sparse) { CHECK(sparse_alloc(c)); CHECK(sparse_base_pass(c)); }
+    if (sparse) { CHECK(sparse_alloc(c, chunk)); CHECK(sparse_base_pass(c)); }
     if (c->dither) { hipLaunchKernelGGL(k_reset_best, dim3(1), dim3(64), 0, c->stream, c->d_bestrecs_all, (int)c->nlanes); c->best_valid = true; }
     if (nl > 1) {
         HIPCHK(hipEventRecord(c->ev_ready, c->stream)); // pack, tables, candidates are ready
         for (uint32_t l = 1; l < nl; l++) HIPCHK(hipStreamWaitEvent(c->extra[l - 1].stream, c->ev_ready, 0));
     }
     uint32_t i = 0;
-    for (uint32_t c0 = 0; c0 < n; c0 += c->chunk, i++) {
-        const uint32_t nc = (n - c0 < c->chunk) ? (n - c0) : c->chunk;
+    for (uint32_t c0 = 0; c0 < n; c0 += chunk, i++) {
+        const uint32_t nc = (n - c0 < chunk) ? (n - c0) : chunk;
         const uint32_t lane = i % nl;
         uint8_t *mo = d_maps_out ? d_maps_out + (size_t)c0 * c->npx : nullptr;
         const int eo = err_offset + (int)c0 * err_stride;
@@ -551,7 +558,7 @@ int32_t do_optimize(snesimage_ctx *c, bool may_skip = false) {
         c->pack_valid = false;
         CHECK(run_prep(c, 0, -1, -1));
     } else {
-        CHECK(alloc_workspace(c, c->chunk));
+        CHECK(alloc_workspace(c, 1));
         if (c->perceptual) CHECK(ensure_source(c));
         // single pseudo-candidate whose slot index matches nothing
         hipLaunchKernelGGL(k_candidate_tables, dim3(1), dim3(64), 0, c->stream, c->d_dummy_cand, 1, c->d_eotf, c->d_cand_tab);
@@ -571,7 +578,7 @@ int32_t do_optimize(snesimage_ctx *c, bool may_skip = false) {
 // error() of the stored palette_map -> d_out (device)
 int32_t do_error(snesimage_ctx *c, double *d_out) {
     CHECK(ensure_map(c));
-    CHECK(alloc_workspace(c, c->chunk));
+    CHECK(alloc_workspace(c, 1));
     CHECK(ensure_tables(c));
     CHECK(ensure_source(c));
     bool saved_dither = c->dither;
@@ -860,13 +867,14 @@ int32_t snesimage_remap_candidates_device(snesimage_ctx *c, uint32_t palette, ui
     if (!d_rgb5 || !d_maps_out) return fail(SNES_ERR_ARG, "null pointer");
     if (n == 0) return SNES_OK;
     CHECK(set_device(c));
-    CHECK(alloc_workspace(c, c->chunk));
+    const uint32_t chunk = n < c->chunk ? n : c->chunk;
+    CHECK(alloc_workspace(c, chunk));
     CHECK(ensure_tables(c));
     if (c->perceptual) CHECK(ensure_source(c));
     CHECK(prep_for_slot(c, (int)palette, (int)index));
     const uint32_t slot_ci = palette * c->sub_size + index;
-    for (uint32_t c0 = 0; c0 < n; c0 += c->chunk) {
-        const uint32_t nc = (n - c0 < c->chunk) ? (n - c0) : c->chunk;
+    for (uint32_t c0 = 0; c0 < n; c0 += chunk) {
+        const uint32_t nc = (n - c0 < chunk) ? (n - c0) : chunk;
         const uint8_t *rgb5 = d_rgb5 + 3 * (size_t)c0;
         uint8_t *maps = d_maps_out + (size_t)c0 * c->npx;
         hipLaunchKernelGGL(k_candidate_tables, dim3((nc + 63) / 64), dim3(64), 0, c->stream, rgb5, (int)nc, c->d_eotf, c->d_cand_tab);
