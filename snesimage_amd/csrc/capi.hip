@@ -133,7 +133,7 @@ struct snesimage_ctx {
         bool enabled = false, side = true; uint32_t min_n = 64; uint32_t cap = 0; // cap = candidates per lane the arrays were sized for
         SparseGeom S{};
         float *store = nullptr, *cand_tab = nullptr, *cand_lab = nullptr, *ckf = nullptr; uint32_t *bitmap = nullptr; double *cka = nullptr, *part = nullptr;
-        CandMeta *meta = nullptr; unsigned int *items = nullptr; int *item_count = nullptr; long long item_stride = 0; int *order = nullptr;
+        CandMeta *meta = nullptr; unsigned int *items = nullptr; int *item_count = nullptr; long long item_stride = 0; int *order = nullptr, *first = nullptr;
         uint4 *plist = nullptr; int *plist_count = nullptr; bool plist_valid = false;
         hipStream_t base_stream = nullptr; hipEvent_t ev_base_in = nullptr, ev_base_done = nullptr; // B's H and V passes run beside the candidates' scan/down/H
     } sp;
@@ -418,6 +418,7 @@ int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
     HIPCHK(hipMalloc(&sp.part, sizeof(double) * ncap * kMaxScales * 18));
     HIPCHK(hipMalloc(&sp.meta, sizeof(CandMeta) * ncap));
     dfree(sp.order); HIPCHK(hipMalloc(&sp.order, sizeof(int) * ncap));
+    dfree(sp.first); HIPCHK(hipMalloc(&sp.first, sizeof(int) * ncap));
     HIPCHK(hipMalloc(&sp.items, sizeof(unsigned int) * (size_t)sp.item_stride * kMaxScales * (c->nlanes + 1)));
     if (!sp.base_stream && sp.side) {
         int prio_lo = 0, prio_hi = 0; // B's sweeps are the critical path of a step: give them the highest stream priority
@@ -445,7 +446,7 @@ SparseParams sparse_params(snesimage_ctx *c, uint32_t lane) {
     P.img1C4 = c->d_img1C4; P.img1R4 = c->d_img1R4; P.mu1R4 = c->d_mu1R4; P.s11R4 = c->d_s11R4;
     P.store = sp.store; P.meta = sp.meta;
     P.items = sp.items + (size_t)lane * sp.item_stride * kMaxScales; P.item_count = sp.item_count + (size_t)lane * kMaxScales; P.item_stride = sp.item_stride; // lane == nlanes: B
-    P.ckf = sp.ckf; P.cka = sp.cka; P.part = sp.part;
+    P.ckf = sp.ckf; P.cka = sp.cka; P.part = sp.part; P.first = sp.first;
     return P;
 }
 
@@ -495,7 +496,7 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
       hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)gx, (unsigned)G.nscales), dim3(64), 0, stream, P); }
     if (sp.side || stream != c->stream) HIPCHK(hipStreamWaitEvent(stream, sp.side ? sp.ev_base_done : c->ev_ready, 0)); // checkpoints and H output of B
     if (c->timing) { HIPCHK(hipEventRecord(tr.ev[2], stream)); HIPCHK(hipEventRecord(tr.ev[3], stream)); }
-    if (c->sp.lpt) { hipLaunchKernelGGL(k_sparse_order, dim3(1), dim3(256), 0, stream, P, sp.order + P.k0); P.order = sp.order + P.k0; }
+    if (c->sp.lpt) { hipLaunchKernelGGL(k_sparse_order, dim3(1), dim3(1024), 0, stream, P, sp.order + P.k0); P.order = sp.order + P.k0; }
     hipLaunchKernelGGL(k_sparse_v, dim3(nc * 3, (unsigned)G.nscales), dim3(256), 0, stream, P);
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[4], stream));
     hipLaunchKernelGGL(k_final_score, dim3((nc + 63) / 64), dim3(64), 0, stream, sp.part + (size_t)P.k0 * G.nscales * 18, (int)nc, G, d_errors, err_stride, err_offset, P.item_count, (int)kMaxScales);
@@ -794,7 +795,7 @@ void snesimage_destroy(snesimage_ctx *c) {
     dfree(c->d_cand); dfree(c->d_cand_sel); dfree(c->d_errs); dfree(c->d_errs_sel); dfree(c->d_inc_err); dfree(c->d_last); dfree(c->d_scratch_err); dfree(c->d_dummy_cand);
     for (auto &L : c->extra) { if (L.stream) (void)hipStreamSynchronize(L.stream); dfree(L.d_mapsC4); dfree(L.d_mapsR4); dfree(L.d_work); dfree(L.d_cand_tab); dfree(L.d_cand_lab); dfree(L.d_part); dfree(L.d_maps); dfree(L.d_mapsT); if (L.done) (void)hipEventDestroy(L.done); if (L.stream) (void)hipStreamDestroy(L.stream); }
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
-    { auto &q = c->sp; if (q.base_stream) { (void)hipStreamSynchronize(q.base_stream); (void)hipStreamDestroy(q.base_stream); (void)hipEventDestroy(q.ev_base_in); (void)hipEventDestroy(q.ev_base_done); } dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.order); dfree(q.cand_lab); dfree(q.bitmap); }
+    { auto &q = c->sp; if (q.base_stream) { (void)hipStreamSynchronize(q.base_stream); (void)hipStreamDestroy(q.base_stream); (void)hipEventDestroy(q.ev_base_in); (void)hipEventDestroy(q.ev_base_done); } dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.order); dfree(q.first); dfree(q.cand_lab); dfree(q.bitmap); }
     kmeans_free(c->km);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;

@@ -61,6 +61,7 @@ struct SparseParams {
     float *store; CandMeta *meta;
     unsigned int *items; int *item_count; long long item_stride; // per scale: items[s*item_stride + i] = cand*256 + slot*4 + ch
     float *ckf; double *cka; double *part;
+    int *first;       // per candidate: first changed group of scale 0 (H/4 if none), written by the scan for k_sparse_order
     const int *order; // k_sparse_v: candidates of the launch, longest column sweeps first (k_sparse_order); nullptr = as listed
 };
 
@@ -137,6 +138,7 @@ __device__ __forceinline__ void sparse_scan_lab_body(const SparseParams &P) {
             if (flag) M->glist[P.S.goff[s] + below] = (unsigned char)lane;
         }
         if (lane == 0) M->ngroups[s] = total;
+        if (lane == 0 && s == 0 && P.first) P.first[k] = m ? __ffsll((long long)m) - 1 : NG;
         const int base = s_off[w][s];
         for (int i = lane; i < total * 3; i += 64) P.items[(size_t)s * P.item_stride + base + i] = (unsigned int)k * 256u + (unsigned int)(i / 3) * 4u + (unsigned int)(i % 3);
         m = pair_or_compress(m);
@@ -230,6 +232,7 @@ __device__ __forceinline__ void sparse_scan_body(const SparseParams &P) {
             if (flag) M->glist[P.S.goff[s] + below] = (unsigned char)lane;
         }
         if (lane == 0) M->ngroups[s] = total;
+        if (lane == 0 && s == 0 && P.first) P.first[k] = m ? __ffsll((long long)m) - 1 : NG;
         const int base = s_off[w][s];
         for (int i = lane; i < total * 3; i += 64) P.items[(size_t)s * P.item_stride + base + i] = (unsigned int)k * 256u + (unsigned int)(i / 3) * 4u + (unsigned int)(i % 3);
         m = pair_or_compress(m);
@@ -831,21 +834,16 @@ __global__ __launch_bounds__(256) void k_remap_won_lab(MapsParams P, const uint4
 __device__ __forceinline__ void sparse_order_body(const SparseParams &P, int *__restrict__ order) {
     __shared__ int s_cnt[66];
     const int t = threadIdx.x, H4 = P.G.sh[0] >> 2;
+    const int *first = P.first + P.k0;
     if (t < 66) s_cnt[t] = 0;
     __syncthreads();
-    for (int i = t; i < P.ncand; i += blockDim.x) {
-        const CandMeta *M = P.meta + P.k0 + i;
-        atomicAdd(&s_cnt[M->ngroups[0] ? (int)M->glist[P.S.goff[0]] : H4], 1);
-    }
+    for (int i = t; i < P.ncand; i += blockDim.x) atomicAdd(&s_cnt[first[i]], 1);
     __syncthreads();
     if (t == 0) { int run = 0; for (int b = 0; b <= H4; b++) { const int c = s_cnt[b]; s_cnt[b] = run; run += c; } }
     __syncthreads();
-    for (int i = t; i < P.ncand; i += blockDim.x) { // the order inside a bin is arbitrary: results do not depend on it
-        const CandMeta *M = P.meta + P.k0 + i;
-        order[atomicAdd(&s_cnt[M->ngroups[0] ? (int)M->glist[P.S.goff[0]] : H4], 1)] = i;
-    }
+    for (int i = t; i < P.ncand; i += blockDim.x) order[atomicAdd(&s_cnt[first[i]], 1)] = i; // arbitrary inside a bin: results do not depend on it
 }
-__global__ __launch_bounds__(256) void k_sparse_order(SparseParams P, int *__restrict__ order) { sparse_order_body(P, order); }
+__global__ __launch_bounds__(1024) void k_sparse_order(SparseParams P, int *__restrict__ order) { sparse_order_body(P, order); }
 
 // ---- kernel entry points of the bodies above ----
 __global__ __launch_bounds__(256) void k_sparse_scan_lab(SparseParams P) { sparse_scan_lab_body(P); }
