@@ -78,6 +78,14 @@ SNES_HD float ciede_hprime(float b, float ap) {
     float r = d_atan2f(b, ap) * (float)(180.0 / 3.14159265358979323846);
     return r < 0.0f ? r + 360.0f : r;
 }
+// A sure "no" for the win test `ciede2000(c1, c2) < bound` (or <= on a tie) without evaluating the formula:
+// dE00^2 = (dL/S_L)^2 + (dC/S_C)^2 + (dH/S_H)^2 + R_T (dC/S_C)(dH/S_H) with |R_T| <= 2, so the last three terms are at
+// least (|dC/S_C| - |dH/S_H|)^2 >= 0 and dE00 >= |dL| / S_L; S_L = 1 + 0.015 (Lm-50)^2 / sqrt(20 + (Lm-50)^2) <= 1.7471
+// for Lm in [0,100].  The margin (1.752 against 1.7471: 0.28 %) dwarfs the rounding of the f32 evaluation (~1e-6), so
+// whenever this returns true the computed distance is strictly above the bound.  Random candidate colours differ from a
+// pixel in lightness by far more than the pixel's current error most of the time: this spares ~85 % of the evaluations.
+SNES_HD bool ciede2000_cannot_beat(const Lab &c1, const Lab &c2, float bound) { return fabsf(c1.l - c2.l) > 1.752f * bound; }
+
 // palette::color_difference::Ciede2000 for Lab<_, f32>, kL = kC = kH = 1
 SNES_HD float ciede2000(Lab c1, Lab c2) {
     const float pi_over_180 = (float)(3.14159265358979323846 / 180.0);

@@ -180,8 +180,9 @@ __device__ __forceinline__ uint32_t resolve_ci(unsigned long long pk, uint32_t c
     } else {
         if (thr == 0xffffffffu) return ncol;
         Lab t; t.l = labpx3[0]; t.a = labpx3[1]; t.b = labpx3[2];
-        float d = ciede2000(clab, t);
         float bd = __uint_as_float(thr & 0x7fffffffu);
+        if (ciede2000_cannot_beat(clab, t, bd)) return ci0;
+        float d = ciede2000(clab, t);
         bool win = (d < bd) || ((thr & 0x80000000u) && d == bd);
         return win ? ncol : ci0;
     }

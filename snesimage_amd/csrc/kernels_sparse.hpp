@@ -74,6 +74,7 @@ __device__ __forceinline__ uint32_t won_bit(const uint32_t *bm, int px) { return
 
 // ---- perceptual scan: CIEDE2000 win test per contested pixel, one wave per candidate ------------------------
 __device__ __forceinline__ void sparse_scan_lab_body(const SparseParams &P) {
+    __shared__ uint32_t s_queue[4][128];
     const Geom &G = P.G;
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
@@ -85,24 +86,45 @@ __device__ __forceinline__ void sparse_scan_lab_body(const SparseParams &P) {
         Lab cl; cl.l = P.cand_lab[3 * (size_t)k]; cl.a = P.cand_lab[3 * (size_t)k + 1]; cl.b = P.cand_lab[3 * (size_t)k + 2];
         uint32_t *bm = P.bitmap + (size_t)k * (G.W * G.H / 32);
         const int n = *P.plist_count;
-        for (int i = lane; i < n; i += 64) {
+        auto take = [&](uint32_t px) { // the candidate wins pixel px
+            const int x = (int)(px & (unsigned)(G.W - 1)), y = (int)(px / (unsigned)G.W);
+            atomicOr(&bm[px >> 5], 1u << (px & 31));
+            mask |= 1ull << (y >> 2);
+            xmin = min(xmin, x);
+            won++;
+        };
+        auto full_test = [&](int i) { // the CIEDE2000 evaluation proper
             const uint4 e = P.plist[i];
-            const uint32_t thr = e.z;
-            bool win;
-            if (thr == 0xffffffffu) win = true;
-            else {
-                Lab t; t.l = P.labpx[3 * (size_t)e.x]; t.a = P.labpx[3 * (size_t)e.x + 1]; t.b = P.labpx[3 * (size_t)e.x + 2];
-                const float d = ciede2000(cl, t), bd = __uint_as_float(thr & 0x7fffffffu);
-                win = (d < bd) || ((thr & 0x80000000u) && d == bd); // strict <, ties to the lower index (lib.rs:788-791)
+            Lab t; t.l = P.labpx[3 * (size_t)e.x]; t.a = P.labpx[3 * (size_t)e.x + 1]; t.b = P.labpx[3 * (size_t)e.x + 2];
+            const float d = ciede2000(cl, t), bd = __uint_as_float(e.z & 0x7fffffffu);
+            if ((d < bd) || ((e.z & 0x80000000u) && d == bd)) take(e.x); // strict <, ties to the lower index (lib.rs:788-791)
+        };
+        // Most contested pixels are out of reach on lightness alone (ciede2000_cannot_beat).  A lane that cannot rule its
+        // pixel out queues it; the ~2,000-instruction evaluation then runs on full waves of queued pixels instead of on
+        // the few surviving lanes of every iteration.
+        uint32_t *q = s_queue[w];
+        int queued = 0; // wave-uniform
+        uint4 e_n = make_uint4(0, 0, 0, 0); float l_n = 0.0f; // entry and lightness of the NEXT round, fetched a round ahead
+        if (lane < n) { e_n = P.plist[lane]; l_n = P.labpx[3 * (size_t)e_n.x]; }
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            const uint4 e = e_n; const float tl = l_n;
+            if (i + 64 < n) { e_n = P.plist[i + 64]; l_n = P.labpx[3 * (size_t)e_n.x]; }
+            bool maybe = false;
+            if (i < n) {
+                if (e.z == 0xffffffffu) take(e.x);
+                else maybe = !(fabsf(cl.l - tl) > 1.752f * __uint_as_float(e.z & 0x7fffffffu)); // ciede2000_cannot_beat on the lightness alone
             }
-            if (win) {
-                const int x = (int)(e.x & (unsigned)(G.W - 1)), y = (int)(e.x / (unsigned)G.W);
-                atomicOr(&bm[e.x >> 5], 1u << (e.x & 31));
-                mask |= 1ull << (y >> 2);
-                xmin = min(xmin, x);
-                won++;
+            const unsigned long long mm = __ballot(maybe);
+            if (maybe) q[queued + __popcll(mm & ((1ull << lane) - 1ull))] = (uint32_t)i;
+            queued += __popcll(mm);
+            if (queued >= 64) { // (the queue holds at most 127 entries)
+                full_test((int)q[lane]);
+                queued -= 64;
+                if (lane < queued) { const uint32_t v = q[64 + lane]; q[lane] = v; } // same-wave LDS traffic is ordered
             }
         }
+        if (lane < queued) full_test((int)q[lane]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             mask |= __shfl_xor(mask, o);
@@ -821,8 +843,11 @@ __global__ __launch_bounds__(256) void k_remap_won_lab(MapsParams P, const uint4
         bool win = thr == 0xffffffffu;
         if (!win) {
             Lab t; t.l = P.labpx[3 * (size_t)e.x]; t.a = P.labpx[3 * (size_t)e.x + 1]; t.b = P.labpx[3 * (size_t)e.x + 2];
-            const float d = ciede2000(cl, t), bd = __uint_as_float(thr & 0x7fffffffu);
-            win = (d < bd) || ((thr & 0x80000000u) && d == bd); // strict <, ties to the lower index (lib.rs:788-791)
+            const float bd = __uint_as_float(thr & 0x7fffffffu);
+            if (!ciede2000_cannot_beat(cl, t, bd)) {
+                const float d = ciede2000(cl, t);
+                win = (d < bd) || ((thr & 0x80000000u) && d == bd); // strict <, ties to the lower index (lib.rs:788-791)
+            }
         }
         if (win) map[e.x] = (uint8_t)P.si;
     }
