@@ -99,6 +99,18 @@ int32_t snesimage_step_begin(snesimage_ctx *ctx, uint32_t method, uint32_t palet
                              uint32_t shard_rank, uint32_t shard_count, double *d_errors);
 int32_t snesimage_step_commit(snesimage_ctx *ctx, const double *d_errors);
 
+/* One process, several GPUs: a group borrows one context per device, all created from the same image and brought to
+ * the same state (initialise one, copy tile_palettes and palette to the others, optimize()).  snesimage_group_step is
+ * snesimage_step with the candidates sharded over the members (rank r scores k = r mod N): step_begin on every member,
+ * one grouped RCCL all-reduce(min) of the error vectors on the members' streams, step_commit on every member — the
+ * palettes stay bit-identical on all devices.  n_total as in snesimage_step_begin.  librccl is opened at run time. */
+typedef struct snesimage_group snesimage_group;
+int32_t snesimage_group_create(snesimage_ctx **ctxs, uint32_t n, snesimage_group **out);
+void snesimage_group_destroy(snesimage_group *group);
+int32_t snesimage_group_step(snesimage_group *group, uint32_t method, uint32_t palette, uint32_t index,
+                             uint32_t channel, uint64_t seed, uint64_t step_id, uint32_t n_total,
+                             double *best_error, uint8_t *best_rgb5 /*3*/);
+
 /* Throughput mode — many independent images on one device, one launch per stage of an optimizer call
  * for all of them (the reference runs one image per process: `run()` lib.rs:830-1024 once per file).
  * A batch borrows its contexts (same device, image size, palette geometry and chunk; RGB distance,

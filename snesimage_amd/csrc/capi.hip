@@ -1154,3 +1154,4 @@ int32_t snesimage_debug_math(int32_t device, int32_t op, const float *x, const f
 } // extern "C"
 
 #include "batch_host.inc"
+#include "group_host.inc"

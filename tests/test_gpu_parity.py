@@ -510,3 +510,34 @@ def test_sparse_path_equals_dense_path(S, O, seed, variant, perceptual, monkeypa
     assert e_d == e_s and np.array_equal(b_d, b_s) and np.array_equal(dense.palette_map, sparse.palette_map)
     dense.close()
     sparse.close()
+
+
+# ---- one process, several devices: RCCL inside the library ---------------------------------------------
+def test_group_step_over_rccl_equals_plain_step(S, img256):
+    """snesimage_group_* with the devices this box has (one): step_begin -> grouped ncclAllReduce(min) -> step_commit must
+    reproduce snesimage_step; two contexts on one device are refused (a group takes one context per device)."""
+    import ctypes as C
+    from snesimage_amd import _ffi
+    L = _ffi.load()
+    ref = S.OptimizedImage(img256, 8, 15)
+    ref.initialize_tiles()
+    ref.recalculate_palettes()
+    mem = S.OptimizedImage(img256, 8, 15)
+    mem.tile_palettes = ref.tile_palettes
+    mem.palette = ref.palette
+    mem.optimize()
+    arr = (C.c_void_p * 1)(mem._c)
+    grp = C.c_void_p()
+    assert L.snesimage_group_create(arr, 1, C.byref(grp)) == 0, L.snesimage_last_error()
+    for i, (method, p, idx, ch, n) in enumerate([(0, 0, 0, 0, 40), (0, 5, 9, 0, 200), (1, 2, 3, 1, 0), (0, 0, 0, 0, 40)]):
+        e_ref, b_ref = ref.step(method, p, idx, ch, 6, i, n)
+        err, best = C.c_double(0), np.zeros(3, np.uint8)
+        assert L.snesimage_group_step(grp, method, p, idx, ch, 6, i, n, C.byref(err), best.ctypes.data_as(_ffi._u8p)) == 0, L.snesimage_last_error()
+        assert err.value == e_ref and np.array_equal(best, b_ref)
+        assert np.array_equal(mem.palette, ref.palette) and np.array_equal(mem.palette_map, ref.palette_map)
+    L.snesimage_group_destroy(grp)
+    twin = S.OptimizedImage(img256, 8, 15)
+    arr2 = (C.c_void_p * 2)(mem._c, twin._c)
+    assert L.snesimage_group_create(arr2, 2, C.byref(grp)) == -1 and b"one context per device" in L.snesimage_last_error()
+    for z in (ref, mem, twin):
+        z.close()
