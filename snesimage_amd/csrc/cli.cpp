@@ -56,6 +56,7 @@ void usage() {
             "  -d, --dither\n      --perceptual-palettes\n      --nes\n"
             "      --calls <N>          optimizer calls to run [default: 0]\n      --candidates <N>     random candidates per call [default: 64]\n"
             "      --seed <N>           candidate RNG seed [default: 1]\n      --device <N>         HIP device [default: 0]\n"
+            "      --devices <A,B,..>   shard every call's candidates over these devices (RCCL inside the library)\n"
             "      --tile-palettes <F>  1024-byte tile->subpalette override\n      --resume <F>         start from the palette and tile palettes of a previous JSON output\n"
             "      --preview <F>        write source | result as a PNG\n"
             "      --decode-only        write the decoded source as raw RGBA8 to <TARGET_FILENAME> and stop (no GPU)\n  -h, --help\n  -V, --version\n");
@@ -105,6 +106,7 @@ int main(int argc, char **argv) {
     uint64_t seed = 1;
     int device = 0;
     std::string tile_file, preview_file, resume_file;
+    std::vector<int> devices; // --devices: candidate sharding over several GPUs from this one process
     bool decode_only = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -118,6 +120,7 @@ int main(int argc, char **argv) {
         else if (a == "--candidates") ncand = (uint32_t)strtoul(need("--candidates"), nullptr, 10);
         else if (a == "--seed") seed = strtoull(need("--seed"), nullptr, 0);
         else if (a == "--device") device = atoi(need("--device"));
+        else if (a == "--devices") { for (const char *q = need("--devices"); *q;) { char *end = nullptr; devices.push_back((int)strtol(q, &end, 10)); if (end == q) { fprintf(stderr, "error: invalid value for '--devices'\n"); return 2; } q = *end == ',' ? end + 1 : end; } }
         else if (a == "--tile-palettes") tile_file = need("--tile-palettes");
         else if (a == "--preview") preview_file = need("--preview");
         else if (a == "--resume") resume_file = need("--resume");
@@ -161,6 +164,7 @@ int main(int argc, char **argv) {
         printf("%u %u\n", w, h);
         return 0;
     }
+    if (!devices.empty()) device = devices[0];
     snesimage_ctx *ctx = nullptr;
     if (snesimage_create(rgba.data(), w, h, count, size, flags, device, &ctx) != 0) die(snesimage_last_error());
     if (!resume_file.empty()) { // palette + tile_palettes of an earlier output (src/lib.rs:579-625); the tiles follow from optimize()
@@ -191,6 +195,22 @@ int main(int argc, char **argv) {
         log_info("Generating initial palettes"); // src/lib.rs:985-989
         if (snesimage_recalculate_palettes(ctx) != 0) die(std::string("Unable to recalculate palettes: ") + snesimage_last_error());
     }
+    // --devices: replicas of the initialised state on the other devices, and the group that shards each call over them
+    std::vector<snesimage_ctx *> members{ctx};
+    snesimage_group *group = nullptr;
+    if (!devices.empty()) {
+        std::vector<uint8_t> tp(1024), pal(3 * (size_t)count * size);
+        if (snesimage_get_tile_palettes(ctx, tp.data()) != 0 || snesimage_get_palette_rgb5(ctx, pal.data()) != 0) die(snesimage_last_error());
+        for (size_t d = 1; d < devices.size(); d++) {
+            snesimage_ctx *m = nullptr;
+            if (snesimage_create(rgba.data(), w, h, count, size, flags, devices[d], &m) != 0 || snesimage_set_tile_palettes(m, tp.data()) != 0 || snesimage_set_palette_rgb5(m, pal.data()) != 0 ||
+                snesimage_optimize(m) != 0)
+                die(snesimage_last_error());
+            members.push_back(m);
+        }
+        if (snesimage_group_create(members.data(), (uint32_t)members.size(), &group) != 0) die(snesimage_last_error());
+        log_info("Sharding candidates over " + std::to_string(members.size()) + " device(s)");
+    }
     log_info("Beginning optimization"); // src/lib.rs:992
     uint32_t palette = 0, index = 0, channel = 0, step = 0;
     double last_error = 1.7976931348623157e308;
@@ -200,8 +220,9 @@ int main(int argc, char **argv) {
         snesimage_schedule_next(count, size, (flags & SNES_NES) ? 1 : 0, &palette, &index, &channel, &step, &method);
         snesimage_get_palette_rgb5(ctx, before.data());
         double error = 0.0; uint8_t best[3];
-        if (snesimage_step(ctx, method, p, ix, ch, seed, call, method == SNES_METHOD_RANDOM ? ncand : 0, &error, best) != 0)
-            die(std::string("Unable to optimize palette: ") + snesimage_last_error());
+        const int32_t rc = group ? snesimage_group_step(group, method, p, ix, ch, seed, call, method == SNES_METHOD_RANDOM ? ncand : 0, &error, best)
+                                 : snesimage_step(ctx, method, p, ix, ch, seed, call, method == SNES_METHOD_RANDOM ? ncand : 0, &error, best);
+        if (rc != 0) die(std::string("Unable to optimize palette: ") + snesimage_last_error());
         const uint8_t *b = &before[3 * ((size_t)p * size + ix)];
         if (b[0] != best[0] || b[1] != best[1] || b[2] != best[2]) { // src/lib.rs:222-234
             char m[160];
@@ -233,6 +254,7 @@ int main(int argc, char **argv) {
         fclose(pf);
         log_info("Wrote preview to " + preview_file);
     }
-    snesimage_destroy(ctx);
+    if (group) snesimage_group_destroy(group);
+    for (snesimage_ctx *m : members) snesimage_destroy(m);
     return 0;
 }

@@ -145,3 +145,15 @@ def test_cli_resume_continues_from_a_previous_output(tmp_path):
     (tmp_path / "junk.json").write_text('{"palette":[[1,2]],"tile_palettes":[]}')
     r = run(*base[:1], str(c), *base[1:], "--resume", str(tmp_path / "junk.json"))
     assert r.returncode == 1 and "Error running application:" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_devices_flag_gives_the_single_device_result(tmp_path):
+    """--devices shards every call over the listed GPUs through the library's RCCL group; with the one device of this box
+    the output must equal the plain run byte for byte."""
+    a, b = tmp_path / "a.json", tmp_path / "b.json"
+    args = ["synth:1592590340", "-c", "4", "-s", "7", "--calls", "8", "--candidates", "20", "--seed", "9"]
+    r1 = run(args[0], str(a), *args[1:])
+    r2 = run(args[0], str(b), *args[1:], "--devices", "0")
+    assert r1.returncode == 0 and r2.returncode == 0, r2.stdout + r2.stderr
+    assert "Sharding candidates over 1 device(s)" in r2.stdout and a.read_text() == b.read_text()
