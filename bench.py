@@ -75,6 +75,10 @@ def bench_images(args, torch, dist, S, world, rank, local_rank, device, force_di
     batch = ImageBatch.synthetic(mine, sub_count, sub_size, device=local_rank, candidates=args.batch, host_threads=args.host_threads,
                                  batched=not args.per_image_launches, groups=args.groups, perceptual=args.perceptual)
     batch.initialize(drop_failed=True)  # untimed: TileAssignment + Clustering of every image
+    if batch.dropped and not args.perceptual:
+        # the synthetic RGB images never violate cogset's precondition; a drop here would silently shrink the workload
+        raise SystemExit("bench.py --config images: %d image(s) failed k-means initialisation (%s); the measurement is void"
+                         % (len(batch.dropped), batch.dropped[:8]))
     batch.run(args.warmup)
     torch.cuda.synchronize()
     if world > 1:
@@ -120,8 +124,8 @@ def bench_images(args, torch, dist, S, world, rank, local_rank, device, force_di
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=400, help="timed optimizer calls (default: about one second of device time)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=0,
                     help="candidates per optimizer call per GPU (weak) or in total (strong); default 4096, and the reference's 64 "
                          "(lib.rs:205) for --config images")

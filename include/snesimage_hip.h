@@ -103,7 +103,10 @@ int32_t snesimage_step_commit(snesimage_ctx *ctx, const double *d_errors);
  * the same state (initialise one, copy tile_palettes and palette to the others, optimize()).  snesimage_group_step is
  * snesimage_step with the candidates sharded over the members (rank r scores k = r mod N): step_begin on every member,
  * one grouped RCCL all-reduce(min) of the error vectors on the members' streams, step_commit on every member — the
- * palettes stay bit-identical on all devices.  n_total as in snesimage_step_begin.  librccl is opened at run time. */
+ * palettes stay bit-identical on all devices.  n_total as in snesimage_step_begin.  librccl is opened at run time.
+ * Lifetime: the group borrows its contexts — destroy the group first.  Destroying a member first retires the group
+ * (snesimage_group_step then fails with SNES_ERR_STATE; snesimage_group_destroy is still required).  A context belongs
+ * to at most one group.  A failed step leaves no member with a pending split-phase step. */
 typedef struct snesimage_group snesimage_group;
 int32_t snesimage_group_create(snesimage_ctx **ctxs, uint32_t n, snesimage_group **out);
 void snesimage_group_destroy(snesimage_group *group);
@@ -113,11 +116,13 @@ int32_t snesimage_group_step(snesimage_group *group, uint32_t method, uint32_t p
 
 /* Throughput mode — many independent images on one device, one launch per stage of an optimizer call
  * for all of them (the reference runs one image per process: `run()` lib.rs:830-1024 once per file).
- * A batch borrows its contexts (same device, image size, palette geometry and chunk; RGB distance,
- * no dither): snesimage_batch_step_async is snesimage_step_async for every member — same slot and
+ * A batch borrows its contexts (same device, image size, palette geometry, chunk and distance — RGB redmean or
+ * --perceptual-palettes; no dither): snesimage_batch_step_async is snesimage_step_async for every member — same slot and
  * method, candidate stream of member i keyed (seeds[i], step_id), at most `chunk` candidates — enqueued
- * on the batch's stream.  Any other call on a member context first waits for that stream.  The batch
- * does not own the contexts: destroy it before them. */
+ * on the batch's stream.  Any other call on a member context first waits for that stream, and the first batched call
+ * after such a call waits for the member's own stream; snesimage_set_chunk is refused on a lent context.  The batch does
+ * not own the contexts: destroy it before them (destroying a member first retires the batch: later calls fail with
+ * SNES_ERR_STATE). */
 typedef struct snesimage_batch snesimage_batch;
 int32_t snesimage_batch_create(snesimage_ctx **ctxs, uint32_t n, snesimage_batch **out);
 void snesimage_batch_destroy(snesimage_batch *batch);
@@ -152,11 +157,17 @@ void snesimage_schedule_next(uint32_t sub_count, uint32_t sub_size, int32_t nes,
  * 6 sRGB8->Lab (x holds r,g,b as floats, out 3 per item). Host pointers. */
 int32_t snesimage_debug_math(int32_t device, int32_t op, const float *x, const float *y, uint32_t n,
                              float *out);
-/* Launch timing by the library's own HIP events on the context's stream (bench.py's roofline leg).
- * While enabled, every scoring launch group records events; timing_read() returns the summed
- * milliseconds ms3[0] = whole launch group (all kernels that score one chunk of candidates),
- * ms3[1] = k_hpass at scale 0, ms3[2] = k_vpass at scale 0 (the dominant kernel), the number of
- * launch groups and the candidates they scored since timing was enabled. */
+/* Fault injection for tests: the (n+1)-th workspace allocation made by the library from now on fails as if the
+ * device were out of memory (n < 0 switches the hook off).  A failed grow returns SNES_ERR_HIP and leaves the context
+ * usable: the next call allocates afresh. */
+void snesimage_debug_fail_alloc(int32_t n);
+/* Launch timing by the library's own HIP events on the stream each launch group runs on (bench.py's roofline leg).
+ * While enabled, every scoring launch group records events; timing_read() returns summed milliseconds:
+ *   ms3[0] = the whole launch group (all kernels that score one chunk of candidates);
+ *   ms3[1] = the H pass: k_sparse_h (one launch, every scale) on the group-sparse path, k_hpass* at scale 0 otherwise;
+ *   ms3[2] = the V pass, the dominant kernel: k_sparse_v alone (one launch, every scale; the wait for B's checkpoints
+ *            and k_sparse_order come before the opening event) on the group-sparse path, k_vpass* at scale 0 otherwise;
+ * plus the number of launch groups and the candidates they scored since timing was enabled. */
 int32_t snesimage_timing_enable(snesimage_ctx *ctx, int32_t on);
 int32_t snesimage_timing_read(snesimage_ctx *ctx, double *ms3, uint64_t *launches,
                               uint64_t *candidates);

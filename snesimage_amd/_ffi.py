@@ -62,6 +62,7 @@ SIGNATURES = [
     ("snesimage_random_candidates", None, [C.c_uint64, C.c_uint64, C.c_uint32, _u8p]),
     ("snesimage_schedule_next", None, [C.c_uint32, C.c_uint32, C.c_int32, _u32p, _u32p, _u32p, _u32p, _u32p]),
     ("snesimage_debug_math", C.c_int32, [C.c_int32, C.c_int32, _f32p, _f32p, C.c_uint32, _f32p]),
+    ("snesimage_debug_fail_alloc", None, [C.c_int32]),
     ("snesimage_timing_enable", C.c_int32, [C.c_void_p, C.c_int32]),
     ("snesimage_timing_read", C.c_int32, [C.c_void_p, _f64p, _u64p, _u64p]),
     ("snesimage_last_error", C.c_char_p, []),

@@ -87,6 +87,14 @@ inline uint64_t mix64(uint64_t z) {
 
 template <typename T> void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
 
+// Every workspace allocation goes through dmalloc so that tests can make the n-th one fail (snesimage_debug_fail_alloc):
+// the grow-on-demand allocators must leave the context usable after a failed grow.
+int g_fail_alloc_in = -1; // -1: off; otherwise the number of allocations that still succeed
+template <typename T> hipError_t dmalloc(T **p, size_t bytes) {
+    if (g_fail_alloc_in >= 0) { if (g_fail_alloc_in == 0) { g_fail_alloc_in = -1; *p = nullptr; return hipErrorOutOfMemory; } g_fail_alloc_in--; }
+    return hipMalloc(p, bytes);
+}
+
 } // namespace
 
 struct snesimage_ctx {
@@ -149,6 +157,8 @@ struct snesimage_ctx {
     KmeansWork km{};
 
     struct snesimage_batch *owner = nullptr; // set while the context is lent to a batch (batch_host.inc)
+    struct snesimage_group *group = nullptr; // set while the context is a member of a group (group_host.inc)
+    hipEvent_t ev_own = nullptr;             // marks the end of the work this context queued on its own stream (for its batch)
 
     // cache keys
     bool tables_valid = false, src_valid = false, inc_valid = false;
@@ -167,15 +177,15 @@ namespace {
 
 int32_t alloc_lane(snesimage_ctx *c, uint32_t chunk, float *&d_work, float *&d_cand_tab, float *&d_cand_lab, double *&d_part, uint8_t *&d_maps, uint8_t *&d_mapsT, uint8_t *&d_mapsC4, uint8_t *&d_mapsR4) {
     dfree(d_work); dfree(d_cand_tab); dfree(d_cand_lab); dfree(d_part); dfree(d_maps); dfree(d_mapsT); dfree(d_mapsC4); dfree(d_mapsR4);
-    HIPCHK(hipMalloc(&d_work, sizeof(float) * (size_t)c->G.cand_stride * chunk));
-    HIPCHK(hipMalloc(&d_cand_tab, sizeof(float) * 8 * (size_t)chunk));
-    HIPCHK(hipMalloc(&d_cand_lab, sizeof(float) * 3 * (size_t)chunk));
-    HIPCHK(hipMalloc(&d_part, sizeof(double) * (size_t)chunk * kMaxScales * 18));
+    HIPCHK(dmalloc(&d_work, sizeof(float) * (size_t)c->G.cand_stride * chunk));
+    HIPCHK(dmalloc(&d_cand_tab, sizeof(float) * 8 * (size_t)chunk));
+    HIPCHK(dmalloc(&d_cand_lab, sizeof(float) * 3 * (size_t)chunk));
+    HIPCHK(dmalloc(&d_part, sizeof(double) * (size_t)chunk * kMaxScales * 18));
     if (c->dither) {
-        HIPCHK(hipMalloc(&d_maps, c->npx * (size_t)chunk));
-        HIPCHK(hipMalloc(&d_mapsT, c->npx * (size_t)chunk));
-        HIPCHK(hipMalloc(&d_mapsC4, c->npx * (size_t)chunk));
-        HIPCHK(hipMalloc(&d_mapsR4, c->npx * (size_t)chunk));
+        HIPCHK(dmalloc(&d_maps, c->npx * (size_t)chunk));
+        HIPCHK(dmalloc(&d_mapsT, c->npx * (size_t)chunk));
+        HIPCHK(dmalloc(&d_mapsC4, c->npx * (size_t)chunk));
+        HIPCHK(dmalloc(&d_mapsR4, c->npx * (size_t)chunk));
     }
     return SNES_OK;
 }
@@ -185,6 +195,7 @@ int32_t alloc_workspace(snesimage_ctx *c, uint32_t chunk) {
     if (chunk < c->chunk_alloc) chunk = c->chunk_alloc;
     HIPCHK(hipStreamSynchronize(c->stream));
     for (auto &L : c->extra) HIPCHK(hipStreamSynchronize(L.stream));
+    c->chunk_alloc = 0; // the buffers are about to be released: a failed grow must not leave the old capacity behind
     CHECK(alloc_lane(c, chunk, c->d_work, c->d_cand_tab, c->d_cand_lab, c->d_part, c->d_maps, c->d_mapsT, c->d_mapsC4, c->d_mapsR4));
     if (!c->ev_ready) HIPCHK(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
     while (c->extra.size() + 1 < c->nlanes) {
@@ -195,9 +206,9 @@ int32_t alloc_workspace(snesimage_ctx *c, uint32_t chunk) {
     }
     for (auto &L : c->extra) CHECK(alloc_lane(c, chunk, L.d_work, L.d_cand_tab, L.d_cand_lab, L.d_part, L.d_maps, L.d_mapsT, L.d_mapsC4, L.d_mapsR4));
     if (c->dither && !c->d_bestmaps_all) {
-        HIPCHK(hipMalloc(&c->d_bestmaps_all, c->npx * (size_t)c->nlanes));
-        HIPCHK(hipMalloc(&c->d_bestrecs_all, sizeof(BestRec) * c->nlanes));
-        HIPCHK(hipMalloc(&c->d_skip, sizeof(int)));
+        HIPCHK(dmalloc(&c->d_bestmaps_all, c->npx * (size_t)c->nlanes));
+        HIPCHK(dmalloc(&c->d_bestrecs_all, sizeof(BestRec) * c->nlanes));
+        HIPCHK(dmalloc(&c->d_skip, sizeof(int)));
         c->d_bestmap = c->d_bestmaps_all; c->d_bestrec = c->d_bestrecs_all;
         for (size_t l = 0; l < c->extra.size(); l++) { c->extra[l].d_bestmap = c->d_bestmaps_all + (l + 1) * c->npx; c->extra[l].d_bestrec = c->d_bestrecs_all + (l + 1); }
     }
@@ -207,12 +218,14 @@ int32_t alloc_workspace(snesimage_ctx *c, uint32_t chunk) {
 
 int32_t ensure_cand_capacity(snesimage_ctx *c, uint32_t n) {
     if (c->cand_cap >= n) return SNES_OK;
+    if (c->stream) HIPCHK(hipStreamSynchronize(c->stream)); // the previous list may still be in flight
+    c->cand_cap = 0;
     dfree(c->d_cand); dfree(c->d_cand_sel); dfree(c->d_errs); dfree(c->d_errs_sel);
     uint32_t cap = n < 64 ? 64 : n;
-    HIPCHK(hipMalloc(&c->d_cand, 3 * (size_t)cap));
-    HIPCHK(hipMalloc(&c->d_cand_sel, 3 * (size_t)cap));
-    HIPCHK(hipMalloc(&c->d_errs, sizeof(double) * cap));
-    HIPCHK(hipMalloc(&c->d_errs_sel, sizeof(double) * cap));
+    HIPCHK(dmalloc(&c->d_cand, 3 * (size_t)cap));
+    HIPCHK(dmalloc(&c->d_cand_sel, 3 * (size_t)cap));
+    HIPCHK(dmalloc(&c->d_errs, sizeof(double) * cap));
+    HIPCHK(dmalloc(&c->d_errs_sel, sizeof(double) * cap));
     c->cand_cap = cap;
     return SNES_OK;
 }
@@ -389,6 +402,9 @@ int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
     auto &sp = c->sp;
     if (sp.cap >= need) return SNES_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto &L : c->extra) HIPCHK(hipStreamSynchronize(L.stream));
+    if (sp.base_stream) HIPCHK(hipStreamSynchronize(sp.base_stream));
+    sp.cap = 0; sp.plist_valid = false; // released below: a failed grow must not leave the old capacity behind
     dfree(sp.store); dfree(sp.cand_tab); dfree(sp.ckf); dfree(sp.cka); dfree(sp.part); dfree(sp.meta); dfree(sp.items); dfree(sp.item_count); dfree(sp.plist); sp.plist_count = nullptr;
     const Geom &G = c->G;
     SparseGeom &S = sp.S;
@@ -406,20 +422,20 @@ int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
     S.cand_stride = off;
     const size_t ncap = (size_t)c->nlanes * need + 1; // + the base image B
     sp.item_stride = (long long)need * (G.sh[0] / 4) * 3;
-    HIPCHK(hipMalloc(&sp.store, sizeof(float) * (size_t)S.cand_stride * ncap));
-    HIPCHK(hipMalloc(&sp.cand_tab, sizeof(float) * 8 * ncap));
+    HIPCHK(dmalloc(&sp.store, sizeof(float) * (size_t)S.cand_stride * ncap));
+    HIPCHK(dmalloc(&sp.cand_tab, sizeof(float) * 8 * ncap));
     if (c->perceptual) {
         dfree(sp.cand_lab); dfree(sp.bitmap);
-        HIPCHK(hipMalloc(&sp.cand_lab, sizeof(float) * 3 * ncap));
-        HIPCHK(hipMalloc(&sp.bitmap, sizeof(uint32_t) * (c->npx / 32) * ncap));
+        HIPCHK(dmalloc(&sp.cand_lab, sizeof(float) * 3 * ncap));
+        HIPCHK(dmalloc(&sp.bitmap, sizeof(uint32_t) * (c->npx / 32) * ncap));
     }
-    HIPCHK(hipMalloc(&sp.ckf, sizeof(float) * (size_t)okf));
-    HIPCHK(hipMalloc(&sp.cka, sizeof(double) * (size_t)oka));
-    HIPCHK(hipMalloc(&sp.part, sizeof(double) * ncap * kMaxScales * 18));
-    HIPCHK(hipMalloc(&sp.meta, sizeof(CandMeta) * ncap));
-    dfree(sp.order); HIPCHK(hipMalloc(&sp.order, sizeof(int) * ncap));
-    dfree(sp.first); HIPCHK(hipMalloc(&sp.first, sizeof(int) * ncap));
-    HIPCHK(hipMalloc(&sp.items, sizeof(unsigned int) * (size_t)sp.item_stride * kMaxScales * (c->nlanes + 1)));
+    HIPCHK(dmalloc(&sp.ckf, sizeof(float) * (size_t)okf));
+    HIPCHK(dmalloc(&sp.cka, sizeof(double) * (size_t)oka));
+    HIPCHK(dmalloc(&sp.part, sizeof(double) * ncap * kMaxScales * 18));
+    HIPCHK(dmalloc(&sp.meta, sizeof(CandMeta) * ncap));
+    dfree(sp.order); HIPCHK(dmalloc(&sp.order, sizeof(int) * ncap));
+    dfree(sp.first); HIPCHK(dmalloc(&sp.first, sizeof(int) * ncap));
+    HIPCHK(dmalloc(&sp.items, sizeof(unsigned int) * (size_t)sp.item_stride * kMaxScales * (c->nlanes + 1)));
     if (!sp.base_stream && sp.side) {
         int prio_lo = 0, prio_hi = 0; // B's sweeps are the critical path of a step: give them the highest stream priority
         HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
@@ -427,11 +443,11 @@ int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
         HIPCHK(hipEventCreateWithFlags(&sp.ev_base_in, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sp.ev_base_done, hipEventDisableTiming));
     }
-    HIPCHK(hipMalloc(&sp.item_count, sizeof(int) * (kMaxScales * (c->nlanes + 1) + 1))); // + the contested-pixel count, right behind B's counters
+    HIPCHK(dmalloc(&sp.item_count, sizeof(int) * (kMaxScales * (c->nlanes + 1) + 1))); // + the contested-pixel count, right behind B's counters
     HIPCHK(hipMemsetAsync(sp.item_count, 0, sizeof(int) * (kMaxScales * (c->nlanes + 1) + 1), c->stream)); // every launch group leaves its counters cleared
     sp.plist_count = sp.item_count + (size_t)kMaxScales * (c->nlanes + 1);
     sp.counters_cleared = true;
-    HIPCHK(hipMalloc(&sp.plist, sizeof(uint4) * c->npx));
+    HIPCHK(dmalloc(&sp.plist, sizeof(uint4) * c->npx));
     sp.cap = need; sp.plist_valid = false;
     return SNES_OK;
 }
@@ -495,8 +511,9 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     { size_t gx = ((size_t)nc * (G.sh[0] / 4) * 3 + 15) / 16; if (gx > 2048) gx = 2048; // grid-stride over the item quads
       hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)gx, (unsigned)G.nscales), dim3(64), 0, stream, P); }
     if (sp.side || stream != c->stream) HIPCHK(hipStreamWaitEvent(stream, sp.side ? sp.ev_base_done : c->ev_ready, 0)); // checkpoints and H output of B
-    if (c->timing) { HIPCHK(hipEventRecord(tr.ev[2], stream)); HIPCHK(hipEventRecord(tr.ev[3], stream)); }
+    if (c->timing) HIPCHK(hipEventRecord(tr.ev[2], stream));
     if (c->sp.lpt) { hipLaunchKernelGGL(k_sparse_order, dim3(1), dim3(1024), 0, stream, P, sp.order + P.k0); P.order = sp.order + P.k0; }
+    if (c->timing) HIPCHK(hipEventRecord(tr.ev[3], stream)); // ev[3]..ev[4] bracket k_sparse_v alone (every scale, one launch)
     hipLaunchKernelGGL(k_sparse_v, dim3(nc * 3, (unsigned)G.nscales), dim3(256), 0, stream, P);
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[4], stream));
     hipLaunchKernelGGL(k_final_score, dim3((nc + 63) / 64), dim3(64), 0, stream, sp.part + (size_t)P.k0 * G.nscales * 18, (int)nc, G, d_errors, err_stride, err_offset, P.item_count, (int)kMaxScales);
@@ -781,10 +798,13 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
 }
 
 void batch_forget(struct snesimage_batch *b, snesimage_ctx *c);
+void group_forget(struct snesimage_group *g, snesimage_ctx *c);
 void snesimage_destroy(snesimage_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->owner) batch_forget(c->owner, c); // waits for the batch's stream and retires the batch
+    if (c->group) group_forget(c->group, c); // retires the group: its other members are their own again
+    if (c->ev_own) (void)hipEventDestroy(c->ev_own);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)drain_timing(c);
     dfree(c->d_packC4); dfree(c->d_packR4); dfree(c->d_subC4); dfree(c->d_subR4); dfree(c->d_mapsC4); dfree(c->d_mapsR4); dfree(c->d_img1C4); dfree(c->d_img1R4); dfree(c->d_mu1R4); dfree(c->d_s11R4);
@@ -816,6 +836,7 @@ int32_t snesimage_sync(snesimage_ctx *c) {
 }
 int32_t snesimage_set_chunk(snesimage_ctx *c, uint32_t chunk) {
     if (!c || chunk == 0 || chunk > 65535) return fail(SNES_ERR_ARG, "chunk must be in [1,65535]");
+    if (c->owner) return fail(SNES_ERR_STATE, "the context is lent to a batch, whose launches are sized for the current chunk: destroy the batch first");
     CHECK(set_device(c));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->chunk = chunk;
@@ -1129,6 +1150,9 @@ int32_t snesimage_timing_read(snesimage_ctx *c, double *ms3, uint64_t *launches,
     if (candidates) *candidates = c->t_cands;
     return SNES_OK;
 }
+
+// test hook: the (n+1)-th workspace allocation from now on fails with hipErrorOutOfMemory (n < 0: off)
+void snesimage_debug_fail_alloc(int32_t n) { g_fail_alloc_in = n; }
 
 int32_t snesimage_debug_math(int32_t device, int32_t op, const float *x, const float *y, uint32_t n, float *out) {
     if (!x || !out || n == 0) return fail(SNES_ERR_ARG, "bad arguments");

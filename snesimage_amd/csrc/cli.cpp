@@ -132,6 +132,8 @@ int main(int argc, char **argv) {
     }
     if (pos.size() != 2) { fprintf(stderr, "error: the following required arguments were not provided: <SOURCE_FILENAME> <TARGET_FILENAME>\n"); usage(); return 2; }
     const std::string source = pos[0], target = pos[1];
+    // the JSON keeps 15 colours per subpalette (src/lib.rs:583-593): a larger subpalette cannot be read back from it
+    if (!resume_file.empty() && size > 15) die("--resume needs --subpalette-size <= 15: the output keeps 15 colours per subpalette");
 
     log_info("Using source image: " + source); // src/lib.rs:834
     std::vector<uint8_t> rgba;

@@ -42,6 +42,14 @@ def test_cli_rejects_missing_file(tmp_path):
     assert r.returncode == 1 and "Error running application:" in r.stdout
 
 
+def test_cli_resume_rejects_subpalettes_the_json_cannot_hold(tmp_path):
+    """as_json keeps 15 colours per subpalette (lib.rs:583-593): --resume with a larger -s would read past them."""
+    (tmp_path / "prev.json").write_text(json.dumps({"palette": [0] * 16, "tile_palettes": [0] * 1024, "tiles": []}))
+    r = run("synth:1", str(tmp_path / "o.json"), "-c", "1", "-s", "16", "--resume", str(tmp_path / "prev.json"))
+    assert r.returncode == 1 and "--subpalette-size <= 15" in r.stdout
+    assert not (tmp_path / "o.json").exists()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("extra,count,size,flags", [([], 8, 15, {}), (["-d"], 2, 3, {"dither": True}), (["--nes"], 2, 3, {"nes": True})])
 def test_cli_end_to_end_matches_oracle(tmp_path, O, extra, count, size, flags):

@@ -394,6 +394,41 @@ def test_dither_commit_takes_winner_map(S, O):
 
 
 # ---- size-independent properties at BASELINE's full size ---------------------------------------------
+@pytest.mark.parametrize("flags", [{}, {"dither": True}])
+def test_failed_workspace_grow_leaves_context_usable(S, img256, flags):
+    """a hipMalloc that fails while a grow-on-demand workspace is being enlarged returns SNES_ERR_HIP and must not
+    leave the old capacity behind (the next, smaller call would then launch on freed/null buffers).  Every allocation of a
+    grow is failed in turn; after each failure a small call has to give the same errors as before."""
+    from snesimage_amd import _ffi
+    L = _ffi.load()
+    g = S.OptimizedImage(img256, 8, 15, **flags)
+    g.initialize_tiles()
+    g.recalculate_palettes()
+    small = S.random_candidates(5, 1, 96)
+    want = g.score_candidates(2, 4, small)
+    big_n = 700
+    failures = 0
+    for nth in range(0, 40):
+        big = S.random_candidates(5, 100 + nth, big_n)
+        L.snesimage_debug_fail_alloc(nth)
+        try:
+            g.score_candidates(2, 4, big)
+            grew = True
+        except S.SnesImageError as e:
+            assert e.code == -2
+            grew = False
+            failures += 1
+        finally:
+            L.snesimage_debug_fail_alloc(-1)
+        got = g.score_candidates(2, 4, small)  # shrinks the request after the failed grow
+        assert np.array_equal(got, want)
+        if grew:
+            break
+        big_n += 64  # the retry above re-allocated at the small size: ask for more again
+    assert failures >= 3  # several distinct allocations of the grow were exercised
+    g.close()
+
+
 def test_exact_reconstruction_scores_zero(S):
     rng = np.random.default_rng(21)
     pal5 = rng.integers(0, 32, size=(8, 15, 3)).astype(np.uint8)
@@ -539,5 +574,12 @@ def test_group_step_over_rccl_equals_plain_step(S, img256):
     twin = S.OptimizedImage(img256, 8, 15)
     arr2 = (C.c_void_p * 2)(mem._c, twin._c)
     assert L.snesimage_group_create(arr2, 2, C.byref(grp)) == -1 and b"one context per device" in L.snesimage_last_error()
-    for z in (ref, mem, twin):
+    # lifetime rules (include/snesimage_hip.h): one group per context; a member destroyed first retires the group
+    assert L.snesimage_group_create(arr, 1, C.byref(grp)) == 0
+    grp2 = C.c_void_p()
+    assert L.snesimage_group_create(arr, 1, C.byref(grp2)) == -3 and b"already belongs to a group" in L.snesimage_last_error()
+    mem.close()
+    assert L.snesimage_group_step(grp, 0, 0, 0, 0, 6, 9, 40, None, None) == -3 and b"destroyed" in L.snesimage_last_error()
+    L.snesimage_group_destroy(grp)
+    for z in (ref, twin):
         z.close()

@@ -6,6 +6,7 @@ third-party algorithms (Sharma's CIEDE2000 table, canonical sRGB->Lab values).  
 """
 import json
 import math
+import os
 
 import numpy as np
 import pytest
@@ -338,3 +339,21 @@ def test_oracle_matches_golden(O, name):
     assert float(o.error()).hex() == g["error_hex"]
     errs = o.score_candidates(g["slot"][0], g["slot"][1], O.random_candidates(1, 42, g["ncand"]))
     assert [float(e).hex() for e in errs] == g["cand_errors_hex"]
+
+
+def test_oracle_matches_throughput_golden(O):
+    """The throughput fixture (BASELINE config 5 geometry) is what the oracle gives stepping an image alone; one image is
+    replayed here (the GPU test replays all of them)."""
+    import hashlib
+    import json
+
+    import golden.make_golden as M
+    with open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")) as f:
+        gold = next(c for c in json.load(f)["throughput"] if c["name"] == "cfg5_8x15_rgb_batch")
+    assert [tuple(c) for c in gold["calls"]] == M.THROUGHPUT_CALLS
+    rec = gold["images"][1]  # the transparent-square variant
+    o, errs = M.throughput_image(rec["gid"], rec["seed"], rec["variant"], False)
+    assert o.palette.reshape(-1).tolist() == rec["palette"]
+    assert hashlib.sha256(np.ascontiguousarray(o.palette_map).tobytes()).hexdigest() == rec["map_sha"]
+    assert [float(e).hex() for e in errs] == rec["errors_hex"]
+    assert hashlib.sha256(o.as_json().encode()).hexdigest() == rec["json_sha"]
