@@ -5,6 +5,7 @@
 #include "kernels_opt.hpp"
 #include "kernels_fast.hpp"
 #include "kernels_sparse.hpp"
+#include "kernels_sparse2.hpp"
 #include "kernels_batch.hpp"
 
 #include <hip/hip_runtime.h>
@@ -113,11 +114,11 @@ struct snesimage_ctx {
     // device state
     uint8_t *d_orig = nullptr, *d_tile_pal = nullptr, *d_colors = nullptr, *d_map = nullptr;
     unsigned long long *d_pack = nullptr, *d_packT = nullptr, *d_packC4 = nullptr, *d_packR4 = nullptr;
-    float *d_img1C4 = nullptr, *d_img1R4 = nullptr, *d_mu1R4 = nullptr, *d_s11R4 = nullptr; // blocked copies for the fast kernels
+    float *d_img1C4 = nullptr, *d_mu1R4 = nullptr, *d_sd1R4 = nullptr, *d_a1 = nullptr, *d_a1R4 = nullptr; double *d_r1 = nullptr, *d_r1R4 = nullptr; // blocked copies for the fast kernels; r1: maps_accumulate
     int fast_mask = 0; // bit s: scale s has width and height multiples of 64
     float *d_eotf = nullptr, *d_lab_eotf = nullptr;
     uint32_t *d_pal_rgb8 = nullptr; float *d_pal_lin = nullptr, *d_pal_xyb = nullptr, *d_pal_lab = nullptr;
-    float *d_lin0 = nullptr, *d_img1 = nullptr, *d_img1T = nullptr, *d_mu1 = nullptr, *d_s11 = nullptr;
+    float *d_lin0 = nullptr, *d_img1 = nullptr, *d_img1T = nullptr, *d_mu1 = nullptr, *d_sd1 = nullptr;
     float *d_labpx = nullptr, *d_labpxT = nullptr;
     // per-chunk workspace
     float *d_work = nullptr, *d_cand_tab = nullptr, *d_cand_lab = nullptr;
@@ -138,9 +139,10 @@ struct snesimage_ctx {
     struct Sparse {
         bool lpt = true; // V pass in descending sweep length (SNES_LPT=0: as listed)
         bool counters_cleared = false; // k_prep cleared B's counters for the current pack
+        uint32_t hgrid = 2048; // most blocks per scale of k_sparse_h (grid-stride beyond)
         bool enabled = false, side = true; uint32_t min_n = 64; uint32_t cap = 0; // cap = candidates per lane the arrays were sized for
         SparseGeom S{};
-        float *store = nullptr, *cand_tab = nullptr, *cand_lab = nullptr, *ckf = nullptr; uint32_t *bitmap = nullptr; double *cka = nullptr, *part = nullptr;
+        float *store = nullptr, *cand_tab = nullptr, *cand_lab = nullptr, *ckf = nullptr, *ckh = nullptr; uint32_t *bitmap = nullptr; double *cka = nullptr, *part = nullptr;
         CandMeta *meta = nullptr; unsigned int *items = nullptr; int *item_count = nullptr; long long item_stride = 0; int *order = nullptr, *first = nullptr;
         uint4 *plist = nullptr; int *plist_count = nullptr; bool plist_valid = false;
         hipStream_t base_stream = nullptr; hipEvent_t ev_base_in = nullptr, ev_base_done = nullptr; // B's H and V passes run beside the candidates' scan/down/H
@@ -258,16 +260,18 @@ int32_t ensure_source(snesimage_ctx *c) {
         int ppw = 256 / G.sh[s];
         hipLaunchKernelGGL((k_hpass<false, false>), dim3((3 + ppw - 1) / ppw), dim3(256), 0, c->stream, Hp);
         VParams Vp{}; Vp.G = G; Vp.K = c->K; Vp.s = s; Vp.npairs = 3; Vp.ncol = c->ncol;
-        Vp.img1 = c->d_img1 + G.src_off[s]; Vp.mu1_out = c->d_mu1 + G.src_off[s]; Vp.s11_out = c->d_s11 + G.src_off[s]; Vp.work = c->d_work;
+        Vp.img1 = c->d_img1 + G.src_off[s]; Vp.mu1_out = c->d_mu1 + G.src_off[s]; Vp.sd1_out = c->d_sd1 + G.src_off[s]; Vp.a1_out = c->d_a1 + G.src_off[s]; Vp.r1_out = c->d_r1 + G.src_off[s]; Vp.work = c->d_work;
         int ppv = 256 / G.sw[s];
         hipLaunchKernelGGL((k_vpass<false, true, false>), dim3((3 + ppv - 1) / ppv), dim3(256), 0, c->stream, Vp);
     }
     for (int s = 0; s < G.nscales; s++)
         if ((c->fast_mask & (1 << s)) || c->sp.enabled) { // the row-sparse path reads the blocked layouts at every scale
             const int N = G.sw[s] * G.sh[s];
-            hipLaunchKernelGGL(k_relayout, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_img1 + G.src_off[s], G.sw[s], G.sh[s], c->d_img1R4 + G.src_off[s], c->d_img1C4 + G.src_off[s]);
+            hipLaunchKernelGGL(k_relayout, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_img1 + G.src_off[s], G.sw[s], G.sh[s], (float *)nullptr, c->d_img1C4 + G.src_off[s]);
             hipLaunchKernelGGL(k_relayout, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_mu1 + G.src_off[s], G.sw[s], G.sh[s], c->d_mu1R4 + G.src_off[s], (float *)nullptr);
-            hipLaunchKernelGGL(k_relayout, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_s11 + G.src_off[s], G.sw[s], G.sh[s], c->d_s11R4 + G.src_off[s], (float *)nullptr);
+            hipLaunchKernelGGL(k_relayout, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_sd1 + G.src_off[s], G.sw[s], G.sh[s], c->d_sd1R4 + G.src_off[s], (float *)nullptr);
+            hipLaunchKernelGGL(k_relayout, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_a1 + G.src_off[s], G.sw[s], G.sh[s], c->d_a1R4 + G.src_off[s], (float *)nullptr);
+            hipLaunchKernelGGL(k_relayout_f64, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->d_r1 + G.src_off[s], G.sw[s], G.sh[s], c->d_r1R4 + G.src_off[s]);
         }
     if (c->perceptual)
         hipLaunchKernelGGL(k_pixel_lab, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, c->d_orig, c->d_lab_eotf, (int)c->W, (int)c->H, c->d_labpx, c->d_labpxT);
@@ -286,7 +290,7 @@ int32_t run_prep(snesimage_ctx *c, int mode, int sp, int si) {
     P.W = (int)c->W; P.H = (int)c->H; P.sub_size = (int)c->sub_size; P.ncol = c->ncol; P.mode = mode; P.sp = sp; P.si = si; P.perceptual = c->perceptual ? 1 : 0;
     c->sp.counters_cleared = false;
     if (mode == 2 && c->sp.plist_count) { // B's item counters (lane index nlanes) and the contested-pixel count sit side by side
-        P.zero = c->sp.item_count + (size_t)c->nlanes * kMaxScales; P.nzero = kMaxScales + 1; c->sp.counters_cleared = true;
+        P.zero = c->sp.item_count + (size_t)c->nlanes * kItemLists; P.nzero = kItemLists + 1; c->sp.counters_cleared = true;
     }
     hipLaunchKernelGGL(k_prep, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, P);
     HIPCHK(hipGetLastError());
@@ -346,7 +350,7 @@ int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double
         F.packC4 = c->d_packC4; F.packR4 = c->d_packR4; F.pal_xyb = c->d_pal_xyb; F.cand_tab = c->d_cand_tab;
         F.use_maps = use_maps ? 1 : 0; F.mapsC4 = reinterpret_cast<const uint32_t *>(c->d_mapsC4); F.mapsR4 = reinterpret_cast<const uint32_t *>(c->d_mapsR4);
         F.subC4 = reinterpret_cast<const uint32_t *>(c->d_subC4); F.subR4 = reinterpret_cast<const uint32_t *>(c->d_subR4);
-        F.img1C4 = c->d_img1C4 + G.src_off[s]; F.img1R4 = c->d_img1R4 + G.src_off[s]; F.mu1R4 = c->d_mu1R4 + G.src_off[s]; F.s11R4 = c->d_s11R4 + G.src_off[s];
+        F.img1C4 = c->d_img1C4 + G.src_off[s]; F.mu1R4 = c->d_mu1R4 + G.src_off[s]; F.sd1R4 = c->d_sd1R4 + G.src_off[s]; F.a1R4 = c->d_a1R4 + G.src_off[s]; F.r1R4 = c->d_r1R4 + G.src_off[s];
         F.work = c->d_work; F.part = c->d_part;
         return F;
     };
@@ -380,7 +384,7 @@ int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double
         } else {
             VParams Vp{}; Vp.G = G; Vp.K = c->K; Vp.s = s; Vp.npairs = npairs; Vp.ncol = c->ncol; Vp.perceptual = c->perceptual ? 1 : 0; Vp.use_maps = use_maps ? 1 : 0; Vp.sub_size = (int)c->sub_size;
             Vp.pack = c->d_pack; Vp.pal_xyb = c->d_pal_xyb; Vp.cand_tab = c->d_cand_tab; Vp.cand_lab = c->d_cand_lab; Vp.labpx = c->d_labpx;
-            Vp.img1 = c->d_img1 + G.src_off[s]; Vp.mu1 = c->d_mu1 + G.src_off[s]; Vp.s11 = c->d_s11 + G.src_off[s]; Vp.work = c->d_work; Vp.part = c->d_part;
+            Vp.mu1 = c->d_mu1 + G.src_off[s]; Vp.sd1 = c->d_sd1 + G.src_off[s]; Vp.a1 = c->d_a1 + G.src_off[s]; Vp.r1 = c->d_r1 + G.src_off[s]; Vp.work = c->d_work; Vp.part = c->d_part;
             Vp.maps = c->d_maps; Vp.tile_pal = c->d_tile_pal;
             if (s == 0) {
                 if (c->perceptual && !use_maps) hipLaunchKernelGGL((k_vpass<true, false, true>), grid, dim3(256), 0, c->stream, Vp);
@@ -408,15 +412,16 @@ int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
     dfree(sp.store); dfree(sp.cand_tab); dfree(sp.ckf); dfree(sp.cka); dfree(sp.part); dfree(sp.meta); dfree(sp.items); dfree(sp.item_count); dfree(sp.plist); sp.plist_count = nullptr;
     const Geom &G = c->G;
     SparseGeom &S = sp.S;
-    long long off = 0, okf = 0, oka = 0; int go = 0;
+    long long off = 0, okf = 0, oka = 0, okh = 0; int go = 0;
     for (int s = 0; s < G.nscales; s++) {
         const long long N = (long long)G.sw[s] * G.sh[s];
         S.off_lin[s] = off; if (s >= 1) off += 3 * N;
         S.off_xybC[s] = off; if (s >= 1) off += 3 * N;
-        S.off_xybR[s] = off; if (s >= 1) off += 3 * N;
+        S.off_xybR[s] = off; off += 3 * N; // scale 0 as well: written by the H pass (kernels_sparse2.hpp), read by the V pass
         S.off_hout[s] = off; off += 9 * N;
         S.off_ckf[s] = okf; okf += 3LL * (G.sh[s] / 4 + 2) * 18 * G.sw[s];
         S.off_cka[s] = oka; oka += 3LL * (G.sh[s] / 4 + 2) * 6 * G.sw[s];
+        S.off_ckh[s] = okh; if (G.sw[s] >= 64) okh += 3LL * 3 * 18 * G.sh[s];
         S.goff[s] = go; go += G.sh[s] / 4;
     }
     S.cand_stride = off;
@@ -430,12 +435,13 @@ int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
         HIPCHK(dmalloc(&sp.bitmap, sizeof(uint32_t) * (c->npx / 32) * ncap));
     }
     HIPCHK(dmalloc(&sp.ckf, sizeof(float) * (size_t)okf));
+    dfree(sp.ckh); HIPCHK(dmalloc(&sp.ckh, sizeof(float) * (size_t)(okh ? okh : 1)));
     HIPCHK(dmalloc(&sp.cka, sizeof(double) * (size_t)oka));
     HIPCHK(dmalloc(&sp.part, sizeof(double) * ncap * kMaxScales * 18));
     HIPCHK(dmalloc(&sp.meta, sizeof(CandMeta) * ncap));
     dfree(sp.order); HIPCHK(dmalloc(&sp.order, sizeof(int) * ncap));
     dfree(sp.first); HIPCHK(dmalloc(&sp.first, sizeof(int) * ncap));
-    HIPCHK(dmalloc(&sp.items, sizeof(unsigned int) * (size_t)sp.item_stride * kMaxScales * (c->nlanes + 1)));
+    HIPCHK(dmalloc(&sp.items, sizeof(unsigned int) * (size_t)sp.item_stride * kItemLists * (c->nlanes + 1)));
     if (!sp.base_stream && sp.side) {
         int prio_lo = 0, prio_hi = 0; // B's sweeps are the critical path of a step: give them the highest stream priority
         HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
@@ -443,9 +449,9 @@ int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
         HIPCHK(hipEventCreateWithFlags(&sp.ev_base_in, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sp.ev_base_done, hipEventDisableTiming));
     }
-    HIPCHK(dmalloc(&sp.item_count, sizeof(int) * (kMaxScales * (c->nlanes + 1) + 1))); // + the contested-pixel count, right behind B's counters
-    HIPCHK(hipMemsetAsync(sp.item_count, 0, sizeof(int) * (kMaxScales * (c->nlanes + 1) + 1), c->stream)); // every launch group leaves its counters cleared
-    sp.plist_count = sp.item_count + (size_t)kMaxScales * (c->nlanes + 1);
+    HIPCHK(dmalloc(&sp.item_count, sizeof(int) * (kItemLists * (c->nlanes + 1) + 1))); // + the contested-pixel count, right behind B's counters
+    HIPCHK(hipMemsetAsync(sp.item_count, 0, sizeof(int) * (kItemLists * (c->nlanes + 1) + 1), c->stream)); // every launch group leaves its counters cleared
+    sp.plist_count = sp.item_count + (size_t)kItemLists * (c->nlanes + 1);
     sp.counters_cleared = true;
     HIPCHK(dmalloc(&sp.plist, sizeof(uint4) * c->npx));
     sp.cap = need; sp.plist_valid = false;
@@ -459,10 +465,11 @@ SparseParams sparse_params(snesimage_ctx *c, uint32_t lane) {
     P.pack = c->d_pack; P.packC4 = c->d_packC4; P.packR4 = c->d_packR4; P.plist = sp.plist; P.plist_count = sp.plist_count;
     P.pal_lin = c->d_pal_lin; P.pal_xyb = c->d_pal_xyb; P.cand_tab = sp.cand_tab;
     P.perceptual = c->perceptual ? 1 : 0; P.labpx = c->d_labpx; P.cand_lab = sp.cand_lab; P.bitmap = sp.bitmap;
-    P.img1C4 = c->d_img1C4; P.img1R4 = c->d_img1R4; P.mu1R4 = c->d_mu1R4; P.s11R4 = c->d_s11R4;
+    P.img1C4 = c->d_img1C4; P.mu1R4 = c->d_mu1R4; P.sd1R4 = c->d_sd1R4; P.a1R4 = c->d_a1R4; P.r1R4 = c->d_r1R4;
     P.store = sp.store; P.meta = sp.meta;
-    P.items = sp.items + (size_t)lane * sp.item_stride * kMaxScales; P.item_count = sp.item_count + (size_t)lane * kMaxScales; P.item_stride = sp.item_stride; // lane == nlanes: B
-    P.ckf = sp.ckf; P.cka = sp.cka; P.part = sp.part; P.first = sp.first;
+    P.items = sp.items + (size_t)lane * sp.item_stride * kItemLists; P.item_count = sp.item_count + (size_t)lane * kItemLists; P.item_stride = sp.item_stride; // lane == nlanes: B
+    P.ckf = sp.ckf; P.cka = sp.cka; P.part = sp.part; P.first = sp.first; P.ckh = sp.ckh;
+    for (P.s_first = 0; P.s_first < c->G.nscales && c->G.sw[P.s_first] >= 64; P.s_first++) {} // first narrow scale
     return P;
 }
 
@@ -471,7 +478,7 @@ int32_t sparse_base_pass(snesimage_ctx *c) {
     auto &sp = c->sp;
     const Geom &G = c->G;
     if (!sp.plist_valid) {
-        if (!sp.counters_cleared) HIPCHK(hipMemsetAsync(sp.item_count + (size_t)c->nlanes * kMaxScales, 0, sizeof(int) * (kMaxScales + 1), c->stream)); // normally k_prep did it
+        if (!sp.counters_cleared) HIPCHK(hipMemsetAsync(sp.item_count + (size_t)c->nlanes * kItemLists, 0, sizeof(int) * (kItemLists + 1), c->stream)); // normally k_prep did it
         sp.counters_cleared = false; // about to be used
         hipLaunchKernelGGL(k_build_plist, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, c->d_pack, (int)c->npx, sp.plist, sp.plist_count);
         SparseParams P = sparse_params(c, c->nlanes); // B has its own item list and counters
@@ -484,8 +491,10 @@ int32_t sparse_base_pass(snesimage_ctx *c) {
         // add cross-queue waits.)
         hipStream_t bs = sp.side ? sp.base_stream : c->stream;
         if (sp.side) { HIPCHK(hipEventRecord(sp.ev_base_in, c->stream)); HIPCHK(hipStreamWaitEvent(bs, sp.ev_base_in, 0)); }
-        hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((G.sh[0] / 4 * 3 + 15) / 16), (unsigned)G.nscales), dim3(64), 0, bs, P);
-        hipLaunchKernelGGL(k_sparse_v_base, dim3(3, (unsigned)G.nscales), dim3(256), 0, bs, P);
+        // wide scales: B rows start at column 0 (list s*kColBuckets) and leave the per-block H checkpoints and the scale-0 XYB plane
+        hipLaunchKernelGGL(k_sparse_h2, dim3((unsigned)((G.sh[0] / 4 * 3 + 15) / 16), (unsigned)(P.s_first * kColBuckets)), dim3(64), 0, bs, P);
+        if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((G.sh[P.s_first] / 4 * 3 + 15) / 16), (unsigned)(G.nscales * kColBuckets)), dim3(64), 0, bs, P);
+        { SparseParams Pv = P; Pv.s_first = 0; hipLaunchKernelGGL(k_sparse_v_base, dim3(3, (unsigned)G.nscales), dim3(256), 0, bs, Pv); }
         HIPCHK(hipGetLastError());
         if (sp.side) HIPCHK(hipEventRecord(sp.ev_base_done, bs));
         sp.plist_valid = true;
@@ -508,15 +517,17 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     } else hipLaunchKernelGGL(k_sparse_scan, dim3((nc + 15) / 16), dim3(1024), 0, stream, P);
     hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P, 0);
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[1], stream));
-    { size_t gx = ((size_t)nc * (G.sh[0] / 4) * 3 + 15) / 16; if (gx > 2048) gx = 2048; // grid-stride over the item quads
-      hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)gx, (unsigned)G.nscales), dim3(64), 0, stream, P); }
+    { size_t gx = ((size_t)nc * (G.sh[0] / 4) * 3 + 15) / 16; if (gx > sp.hgrid) gx = sp.hgrid; // grid-stride over the item quads
+      hipLaunchKernelGGL(k_sparse_h2, dim3((unsigned)gx, (unsigned)(P.s_first * kColBuckets)), dim3(64), 0, stream, P);
+      if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((gx + 7) / 8), (unsigned)(G.nscales * kColBuckets)), dim3(64), 0, stream, P); }
     if (sp.side || stream != c->stream) HIPCHK(hipStreamWaitEvent(stream, sp.side ? sp.ev_base_done : c->ev_ready, 0)); // checkpoints and H output of B
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[2], stream));
     if (c->sp.lpt) { hipLaunchKernelGGL(k_sparse_order, dim3(1), dim3(1024), 0, stream, P, sp.order + P.k0); P.order = sp.order + P.k0; }
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[3], stream)); // ev[3]..ev[4] bracket k_sparse_v alone (every scale, one launch)
-    hipLaunchKernelGGL(k_sparse_v, dim3(nc * 3, (unsigned)G.nscales), dim3(256), 0, stream, P);
+    hipLaunchKernelGGL(k_sparse_v2, dim3(nc * 3, (unsigned)P.s_first), dim3(256), 0, stream, P);
+    if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_v, dim3((nc * 3 + 7) / 8, (unsigned)G.nscales), dim3(256), 0, stream, P); // narrow scales: >= 8 pairs per block
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[4], stream));
-    hipLaunchKernelGGL(k_final_score, dim3((nc + 63) / 64), dim3(64), 0, stream, sp.part + (size_t)P.k0 * G.nscales * 18, (int)nc, G, d_errors, err_stride, err_offset, P.item_count, (int)kMaxScales);
+    hipLaunchKernelGGL(k_final_score, dim3((nc + 63) / 64), dim3(64), 0, stream, sp.part + (size_t)P.k0 * G.nscales * 18, (int)nc, G, d_errors, err_stride, err_offset, P.item_count, (int)kItemLists);
     HIPCHK(hipGetLastError());
     if (c->timing) { HIPCHK(hipEventRecord(tr.ev[5], stream)); c->t_pending.push_back(tr); }
     return SNES_OK;
@@ -723,6 +734,7 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     if (const char *e = getenv("SNES_SPARSE")) c->sp.enabled = c->sp.enabled && atoi(e) != 0;
     if (const char *e = getenv("SNES_BASE_STREAM")) c->sp.side = atoi(e) != 0;
     if (const char *e = getenv("SNES_LPT")) c->sp.lpt = atoi(e) != 0;
+    if (const char *e = getenv("SNES_HGRID")) { int v = atoi(e); if (v >= 1) c->sp.hgrid = (uint32_t)v; }
     if (const char *e = getenv("SNES_SPARSE_MIN")) { int v = atoi(e); if (v >= 1) c->sp.min_n = (uint32_t)v; }
     Geom &G = c->G;
     G.W = (int)w; G.H = (int)h; G.nscales = 0;
@@ -767,11 +779,14 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
         HIPCHK(hipMalloc(&c->d_img1, c->src_floats * 4));
         HIPCHK(hipMalloc(&c->d_img1T, c->src_floats * 4));
         HIPCHK(hipMalloc(&c->d_mu1, c->src_floats * 4));
-        HIPCHK(hipMalloc(&c->d_s11, c->src_floats * 4));
+        HIPCHK(hipMalloc(&c->d_sd1, c->src_floats * 4));
+        HIPCHK(hipMalloc(&c->d_a1, c->src_floats * 4));
+        HIPCHK(hipMalloc(&c->d_a1R4, c->src_floats * 4));
+        HIPCHK(hipMalloc(&c->d_r1, c->src_floats * 8));
+        HIPCHK(hipMalloc(&c->d_r1R4, c->src_floats * 8));
         HIPCHK(hipMalloc(&c->d_img1C4, c->src_floats * 4));
-        HIPCHK(hipMalloc(&c->d_img1R4, c->src_floats * 4));
         HIPCHK(hipMalloc(&c->d_mu1R4, c->src_floats * 4));
-        HIPCHK(hipMalloc(&c->d_s11R4, c->src_floats * 4));
+        HIPCHK(hipMalloc(&c->d_sd1R4, c->src_floats * 4));
         if (c->perceptual) { HIPCHK(hipMalloc(&c->d_labpx, c->npx * 3 * 4)); HIPCHK(hipMalloc(&c->d_labpxT, c->npx * 3 * 4)); }
         HIPCHK(hipMalloc(&c->d_inc_err, sizeof(double)));
         HIPCHK(hipMalloc(&c->d_scratch_err, sizeof(double)));
@@ -807,15 +822,15 @@ void snesimage_destroy(snesimage_ctx *c) {
     if (c->ev_own) (void)hipEventDestroy(c->ev_own);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)drain_timing(c);
-    dfree(c->d_packC4); dfree(c->d_packR4); dfree(c->d_subC4); dfree(c->d_subR4); dfree(c->d_mapsC4); dfree(c->d_mapsR4); dfree(c->d_img1C4); dfree(c->d_img1R4); dfree(c->d_mu1R4); dfree(c->d_s11R4);
+    dfree(c->d_packC4); dfree(c->d_packR4); dfree(c->d_subC4); dfree(c->d_subR4); dfree(c->d_mapsC4); dfree(c->d_mapsR4); dfree(c->d_img1C4); dfree(c->d_mu1R4); dfree(c->d_sd1R4); dfree(c->d_r1); dfree(c->d_r1R4); dfree(c->d_a1); dfree(c->d_a1R4);
     dfree(c->d_orig); dfree(c->d_tile_pal); dfree(c->d_colors); dfree(c->d_map); dfree(c->d_pack); dfree(c->d_packT); dfree(c->d_eotf); dfree(c->d_lab_eotf);
-    dfree(c->d_pal_rgb8); dfree(c->d_pal_lin); dfree(c->d_pal_xyb); dfree(c->d_pal_lab); dfree(c->d_lin0); dfree(c->d_img1); dfree(c->d_img1T); dfree(c->d_mu1); dfree(c->d_s11);
+    dfree(c->d_pal_rgb8); dfree(c->d_pal_lin); dfree(c->d_pal_xyb); dfree(c->d_pal_lab); dfree(c->d_lin0); dfree(c->d_img1); dfree(c->d_img1T); dfree(c->d_mu1); dfree(c->d_sd1);
     dfree(c->d_bestmaps_all); dfree(c->d_bestrecs_all); dfree(c->d_skip); dfree(c->d_rplist); dfree(c->d_rcount);
     dfree(c->d_labpx); dfree(c->d_labpxT); dfree(c->d_work); dfree(c->d_cand_tab); dfree(c->d_cand_lab); dfree(c->d_part); dfree(c->d_maps); dfree(c->d_mapsT);
     dfree(c->d_cand); dfree(c->d_cand_sel); dfree(c->d_errs); dfree(c->d_errs_sel); dfree(c->d_inc_err); dfree(c->d_last); dfree(c->d_scratch_err); dfree(c->d_dummy_cand);
     for (auto &L : c->extra) { if (L.stream) (void)hipStreamSynchronize(L.stream); dfree(L.d_mapsC4); dfree(L.d_mapsR4); dfree(L.d_work); dfree(L.d_cand_tab); dfree(L.d_cand_lab); dfree(L.d_part); dfree(L.d_maps); dfree(L.d_mapsT); if (L.done) (void)hipEventDestroy(L.done); if (L.stream) (void)hipStreamDestroy(L.stream); }
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
-    { auto &q = c->sp; if (q.base_stream) { (void)hipStreamSynchronize(q.base_stream); (void)hipStreamDestroy(q.base_stream); (void)hipEventDestroy(q.ev_base_in); (void)hipEventDestroy(q.ev_base_done); } dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.order); dfree(q.first); dfree(q.cand_lab); dfree(q.bitmap); }
+    { auto &q = c->sp; if (q.base_stream) { (void)hipStreamSynchronize(q.base_stream); (void)hipStreamDestroy(q.base_stream); (void)hipEventDestroy(q.ev_base_in); (void)hipEventDestroy(q.ev_base_done); } dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.order); dfree(q.first); dfree(q.cand_lab); dfree(q.bitmap); dfree(q.ckh); }
     kmeans_free(c->km);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;

@@ -406,6 +406,44 @@ __global__ __launch_bounds__(256) void k_source_scale0(const uint8_t *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// ssim_map + edge_diff_map of one pixel (ssimulacra2 0.5.1), added to the six pooling sums of its column
+// {d, d^4, artifact, artifact^4, detail_lost, detail_lost^4}.  Shared by every V-pass flavour, so that all of them (and
+// B's checkpoints) hold bit-identical sums.
+// The source side is precomputed once per image (k_vpass<.., SRC = true>): sd1 = sigma11 - mu1*mu1 and a1 = |img1 - mu1|,
+// the binary32 values the crate forms per call, and r1 = 1 / (1 + a1) in binary64.  The crate's
+//     d1 = (1 + |img2 - mu2|) / (1 + |img1 - mu1|) - 1        (binary64)
+// is evaluated as (|img2 - mu2| - a1) * r1: equal in exact arithmetic, within 3.3e-16 RELATIVE in binary64 (the
+// difference of two binary32 values widened to binary64, one rounding of r1, one of the product) and exactly 0 where the
+// quotient form is (a reconstruction identical to the source scores exactly 100) — ~1e-15 relative on the pooled
+// sums, ten orders below the 1e-5 the error may move.  It replaces a binary64 division per pixel and channel (a quarter
+// of the V pass's issue slots) by a subtraction and a product.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void maps_accumulate(double (&acc)[6], float m1, float sd1, float a1, double r1, float m2, float v22, float v12, float i2) {
+    const float mu22 = m2 * m2, mu12 = m1 * m2;
+    const float mu_diff = m1 - m2;
+    const float num_m = fmaf(mu_diff, -mu_diff, 1.0f);
+    const float num_s = fmaf(2.0f, v12 - mu12, 0.0009f);
+    const float denom_s = sd1 + (v22 - mu22) + 0.0009f;
+    double d = 1.0 - (double)((num_m * num_s) / denom_s);
+    d = d > 0.0 ? d : 0.0;
+    acc[0] += d;
+    const double dd = d * d;
+    acc[1] += dd * dd;
+    const double d1 = ((double)fabsf(i2 - m2) - (double)a1) * r1;
+    const double art = d1 > 0.0 ? d1 : 0.0;
+    const double det = (-d1) > 0.0 ? (-d1) : 0.0;
+    acc[2] += art;
+    const double a2 = art * art;
+    acc[3] += a2 * a2;
+    acc[4] += det;
+    const double l2 = det * det;
+    acc[5] += l2 * l2;
+}
+__device__ __forceinline__ float source_sd1(float mu1, float sigma11) { const float mu11 = mu1 * mu1; return sigma11 - mu11; }
+__device__ __forceinline__ float source_a1(float img1, float mu1) { return fabsf(img1 - mu1); }
+__device__ __forceinline__ double source_r1(float a1) { return 1.0 / (1.0 + (double)a1); }
+
+// ------------------------------------------------------------------------------------------------
 // Horizontal pass of the recursive Gaussian (ssimulacra2 blur/gaussian.rs horizontal_row) for the
 // three planes of one (candidate, channel) pair: mu2 <- img2, s22 <- img2^2, s12 <- img1*img2.
 // thread = one image row (the recurrence runs along x and cannot be split without changing its
@@ -542,8 +580,8 @@ struct VParams {
     Geom G; BlurK K;
     int s, npairs, ncol, perceptual, use_maps, sub_size, exact_edge;
     const unsigned long long *pack; const float *pal_xyb; const float *cand_tab; const float *cand_lab; const float *labpx;
-    const float *img1, *mu1, *s11; // source arrays + src_off[s]; SRC: mu1/s11 are outputs
-    float *mu1_out, *s11_out;
+    const float *img1, *mu1, *sd1, *a1; const double *r1; // source arrays + src_off[s] (img1: SRC only); see maps_accumulate
+    float *mu1_out, *sd1_out, *a1_out; double *r1_out;   // SRC: what the pass leaves behind
     const float *work; // candidate workspace (hout, xyb)
     double *part;      // [cand][S][3][6]
     const uint8_t *maps; const uint8_t *tile_pal;
@@ -576,9 +614,11 @@ __global__ __launch_bounds__(256) void k_vpass(VParams P) {
     }
     const float *hout = P.work + (size_t)cand * G.cand_stride + G.off_hout[s] + (size_t)(ch * 3) * ns;
     const float *xyb = (S0 || SRC) ? nullptr : P.work + (size_t)cand * G.cand_stride + G.off_xyb[s] + (size_t)ch * ns;
-    const float *img1 = P.img1 + (size_t)ch * ns;
+    const float *img1 = SRC ? P.img1 + (size_t)ch * ns : nullptr;
     const float *mu1 = SRC ? nullptr : P.mu1 + (size_t)ch * ns;
-    const float *s11 = SRC ? nullptr : P.s11 + (size_t)ch * ns;
+    const float *sd1 = SRC ? nullptr : P.sd1 + (size_t)ch * ns;
+    const float *a1 = SRC ? nullptr : P.a1 + (size_t)ch * ns;
+    const double *r1 = SRC ? nullptr : P.r1 + (size_t)ch * ns;
 
     const float n2_0 = P.K.n2[0], n2_1 = P.K.n2[1], n2_2 = P.K.n2[2];
     const float d1_0 = P.K.d1[0], d1_1 = P.K.d1[1], d1_2 = P.K.d1[2];
@@ -622,10 +662,11 @@ __global__ __launch_bounds__(256) void k_vpass(VParams P) {
                 const size_t idx = (size_t)n * W + x;
                 if (SRC) {
                     P.mu1_out[(size_t)ch * ns + idx] = outp[0];
-                    P.s11_out[(size_t)ch * ns + idx] = outp[1];
+                    P.sd1_out[(size_t)ch * ns + idx] = source_sd1(outp[0], outp[1]);
+                    const float a1v = source_a1(img1[idx], outp[0]);
+                    P.a1_out[(size_t)ch * ns + idx] = a1v;
+                    P.r1_out[(size_t)ch * ns + idx] = source_r1(a1v);
                 } else {
-                    const float m1 = mu1[idx], m2 = outp[0], v11 = s11[idx], v22 = outp[1], v12 = outp[2];
-                    const float i1 = img1[idx];
                     float i2;
                     if (S0) {
                         uint32_t ci;
@@ -639,27 +680,7 @@ __global__ __launch_bounds__(256) void k_vpass(VParams P) {
                         } else ci = resolve_ci<PERCEPTUAL>(P.pack[idx], crgb, cl, PERCEPTUAL ? P.labpx + 3 * idx : nullptr, (uint32_t)P.ncol);
                         i2 = (ci == (uint32_t)P.ncol) ? cand_v : s_lut[ch][ci];
                     } else i2 = xyb[idx];
-                    // ssim_map
-                    const float mu11 = m1 * m1, mu22 = m2 * m2, mu12 = m1 * m2;
-                    const float mu_diff = m1 - m2;
-                    const float num_m = fmaf(mu_diff, -mu_diff, 1.0f);
-                    const float num_s = fmaf(2.0f, v12 - mu12, 0.0009f);
-                    const float denom_s = (v11 - mu11) + (v22 - mu22) + 0.0009f;
-                    double d = 1.0 - (double)((num_m * num_s) / denom_s);
-                    d = d > 0.0 ? d : 0.0;
-                    acc[0] += d;
-                    const double dd = d * d;
-                    acc[1] += dd * dd;
-                    // edge_diff_map
-                    const double d1 = (1.0 + (double)fabsf(i2 - m2)) / (1.0 + (double)fabsf(i1 - m1)) - 1.0;
-                    const double art = d1 > 0.0 ? d1 : 0.0;
-                    const double det = (-d1) > 0.0 ? (-d1) : 0.0;
-                    acc[2] += art;
-                    const double a2 = art * art;
-                    acc[3] += a2 * a2;
-                    acc[4] += det;
-                    const double l2 = det * det;
-                    acc[5] += l2 * l2;
+                    maps_accumulate(acc, mu1[idx], sd1[idx], a1[idx], r1[idx], outp[0], outp[1], outp[2], i2);
                 }
             }
         }

@@ -3,7 +3,7 @@
 // arguments sit in a device array instead of the kernel's own argument block.  Every image of a batch has the same
 // geometry and the same number of candidates, so one grid shape serves them all; nothing is shared between images.
 #pragma once
-#include "kernels_sparse.hpp"
+#include "kernels_sparse2.hpp"
 
 namespace snes {
 
@@ -35,10 +35,12 @@ __global__ __launch_bounds__(256) void kb_clear_bitmaps(const BatchArgs *__restr
 }
 __global__ __launch_bounds__(256) void kb_sparse_scan_lab(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; sparse_scan_lab_body(a.Pc); }
 __global__ __launch_bounds__(64) void kb_sparse_h(const BatchArgs *__restrict__ A, int base) { SNES_BATCH_IMG; sparse_h_body(base ? a.Pb : a.Pc); }
+__global__ __launch_bounds__(64) void kb_sparse_h2(const BatchArgs *__restrict__ A, int base) { SNES_BATCH_IMG; sparse_h2_dispatch(base ? a.Pb : a.Pc); }
+__global__ __launch_bounds__(256, 4) void kb_sparse_v2(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; if ((int)blockIdx.y < a.Pc.G.nscales && a.Pc.G.sw[blockIdx.y] >= 64) sparse_v2_body(a.Pc, (int)blockIdx.y); }
 __global__ __launch_bounds__(256, 1) void kb_sparse_v_base(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; sparse_v_base_body(a.Pb); }
 __global__ __launch_bounds__(1024) void kb_sparse_order(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; sparse_order_body(a.Pc, const_cast<int *>(a.Pc.order)); }
-__global__ __launch_bounds__(256, 4) void kb_sparse_v(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; sparse_v_body<false, 2, 2>(a.Pc, (int)blockIdx.y); }
-__global__ void kb_final_score(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; final_score_body(a.part, a.n, a.Pc.G, a.errors, 1, 0, a.Pc.item_count, (int)kMaxScales); }
+__global__ __launch_bounds__(256, 4) void kb_sparse_v(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; if ((int)blockIdx.y >= a.Pc.s_first) sparse_v_body<false, 2, 2>(a.Pc, (int)blockIdx.y); }
+__global__ void kb_final_score(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; final_score_body(a.part, a.n, a.Pc.G, a.errors, 1, 0, a.Pc.item_count, (int)kItemLists); }
 __global__ __launch_bounds__(256) void kb_commit(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; commit_body(a.errors, a.n, a.cand, a.colors, a.slot, a.nes, a.inc_err, a.last, a.T); }
 #undef SNES_BATCH_IMG
 

@@ -29,7 +29,7 @@ struct FastParams {
     int use_maps; const uint32_t *mapsC4, *mapsR4, *subC4, *subR4; // 4 pixels per word, blocked like the pack
     const float *pal_xyb, *cand_tab;
     const float *img1C4;                       // source, this scale: [3][C4]
-    const float *img1R4, *mu1R4, *s11R4;       // source, this scale: [3][R4]
+    const float *mu1R4, *sd1R4, *a1R4; const double *r1R4; // source, this scale: [3][R4] (maps_accumulate)
     float *work; double *part;
 };
 
@@ -206,9 +206,10 @@ __global__ __launch_bounds__(256) void k_vpass_fast(FastParams P) {
     const float4 *h0 = reinterpret_cast<const float4 *>(P.work + (size_t)cand * G.cand_stride + G.off_hout[s] + (size_t)(ch * 3) * ns) + (((size_t)(x >> 6) * H4) << 6) + (x & 63);
     const float4 *h1 = h0 + plane4, *h2 = h1 + plane4;
     // R4: float4 index g*W + x; advances by W per row group
-    const float4 *img1 = reinterpret_cast<const float4 *>(P.img1R4 + (size_t)ch * ns) + x;
     const float4 *mu1 = reinterpret_cast<const float4 *>(P.mu1R4 + (size_t)ch * ns) + x;
-    const float4 *s11 = reinterpret_cast<const float4 *>(P.s11R4 + (size_t)ch * ns) + x;
+    const float4 *sd1 = reinterpret_cast<const float4 *>(P.sd1R4 + (size_t)ch * ns) + x;
+    const float4 *a1 = reinterpret_cast<const float4 *>(P.a1R4 + (size_t)ch * ns) + x;
+    const double2 *r1 = reinterpret_cast<const double2 *>(P.r1R4 + (size_t)ch * ns) + 2 * (size_t)x; // two 16-byte halves per row group
     const float4 *xyb = S0 ? nullptr : reinterpret_cast<const float4 *>(P.work + (size_t)cand * G.cand_stride + G.off_xyb[s] + (size_t)ch * ns) + x;
     const bool use_maps = S0 && P.use_maps;
     const uint32_t slot_ci = S0 ? __float_as_uint(P.cand_tab[8 * (size_t)cand + 7]) : 0u;
@@ -232,7 +233,8 @@ __global__ __launch_bounds__(256) void k_vpass_fast(FastParams P) {
     ring[0][0] = h0[0]; ring[1][0] = h1[0]; ring[2][0] = h2[0];
     h0 += 64; h1 += 64; h2 += 64;
     // map inputs of row group g-1 travel one iteration ahead of their use
-    float4 n_i1 = make_float4(0.f, 0.f, 0.f, 0.f), n_m1 = n_i1, n_s11 = n_i1, n_x = n_i1;
+    float4 n_m1 = make_float4(0.f, 0.f, 0.f, 0.f), n_sd1 = n_m1, n_a1 = n_m1, n_x = n_m1;
+    double2 n_ra = make_double2(1.0, 1.0), n_rb = n_ra;
     uint4 n_pa = make_uint4(0, 0, 0, 0), n_pb = n_pa;
 
     for (int g0 = 0; g0 <= H4; g0 += 5) {
@@ -241,11 +243,11 @@ __global__ __launch_bounds__(256) void k_vpass_fast(FastParams P) {
             const int g = g0 + u;
             if (g > H4) break;
             const int un = (u + 1) % 5, ua = (u + 2) % 5, ub = (u + 3) % 5;
-            const float4 c_i1 = n_i1, c_m1 = n_m1, c_s11 = n_s11, c_x = n_x; const uint4 c_pa = n_pa, c_pb = n_pb;
+            const float4 c_m1 = n_m1, c_sd1 = n_sd1, c_a1 = n_a1, c_x = n_x; const double2 c_ra = n_ra, c_rb = n_rb; const uint4 c_pa = n_pa, c_pb = n_pb;
             if (g + 1 < H4) { ring[0][un] = h0[0]; ring[1][un] = h1[0]; ring[2][un] = h2[0]; h0 += 64; h1 += 64; h2 += 64; }
             else { ring[0][un] = make_float4(0.f, 0.f, 0.f, 0.f); ring[1][un] = ring[0][un]; ring[2][un] = ring[0][un]; }
             if (g < H4) { // inputs of the maps of rows 4g..4g+3, consumed in the next iteration
-                n_i1 = img1[0]; n_m1 = mu1[0]; n_s11 = s11[0]; img1 += W; mu1 += W; s11 += W;
+                n_m1 = mu1[0]; n_sd1 = sd1[0]; n_a1 = a1[0]; n_ra = r1[0]; n_rb = r1[1]; mu1 += W; sd1 += W; a1 += W; r1 += 2 * W;
                 if (use_maps) { n_pa.x = mp[0]; n_pa.y = sbp[0]; mp += W; sbp += W; }
                 else if (S0) { n_pa = pk[0]; n_pb = pk[1]; pk += 2 * (size_t)W; } else { n_x = xyb[0]; xyb += W; }
             }
@@ -256,7 +258,8 @@ __global__ __launch_bounds__(256) void k_vpass_fast(FastParams P) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) i2v[j] = (ci[j] == (uint32_t)P.ncol) ? cand_v : lut[ci[j]];
             }
-            const float i1v[4] = {c_i1.x, c_i1.y, c_i1.z, c_i1.w}, m1v[4] = {c_m1.x, c_m1.y, c_m1.z, c_m1.w}, s11v[4] = {c_s11.x, c_s11.y, c_s11.z, c_s11.w};
+            const float m1v[4] = {c_m1.x, c_m1.y, c_m1.z, c_m1.w}, sd1v[4] = {c_sd1.x, c_sd1.y, c_sd1.z, c_sd1.w}, a1v[4] = {c_a1.x, c_a1.y, c_a1.z, c_a1.w};
+            const double r1v[4] = {c_ra.x, c_ra.y, c_rb.x, c_rb.y};
             float in[3][4], top[3][4];
 #pragma unroll
             for (int p = 0; p < 3; p++) {
@@ -271,29 +274,7 @@ __global__ __launch_bounds__(256) void k_vpass_fast(FastParams P) {
                 } else {
                     SNES_VSTEP(top[0][j] + in[0][j], sb[0], sa[0], outp[0]) SNES_VSTEP(top[1][j] + in[1][j], sb[1], sa[1], outp[1]) SNES_VSTEP(top[2][j] + in[2][j], sb[2], sa[2], outp[2])
                 }
-                if (g >= 1) { // row n = 4(g-1) + j: ssim_map and edge_diff_map terms
-                    const float m1 = m1v[j], m2 = outp[0], v11 = s11v[j], v22 = outp[1], v12 = outp[2];
-                    const float i1 = i1v[j], i2 = i2v[j];
-                    const float mu11 = m1 * m1, mu22 = m2 * m2, mu12 = m1 * m2;
-                    const float mu_diff = m1 - m2;
-                    const float num_m = fmaf(mu_diff, -mu_diff, 1.0f);
-                    const float num_s = fmaf(2.0f, v12 - mu12, 0.0009f);
-                    const float denom_s = (v11 - mu11) + (v22 - mu22) + 0.0009f;
-                    double d = 1.0 - (double)((num_m * num_s) / denom_s);
-                    d = d > 0.0 ? d : 0.0;
-                    acc[0] += d;
-                    const double dd = d * d;
-                    acc[1] += dd * dd;
-                    const double d1 = (1.0 + (double)fabsf(i2 - m2)) / (1.0 + (double)fabsf(i1 - m1)) - 1.0;
-                    const double art = d1 > 0.0 ? d1 : 0.0;
-                    const double det = (-d1) > 0.0 ? (-d1) : 0.0;
-                    acc[2] += art;
-                    const double a2 = art * art;
-                    acc[3] += a2 * a2;
-                    acc[4] += det;
-                    const double l2 = det * det;
-                    acc[5] += l2 * l2;
-                }
+                if (g >= 1) maps_accumulate(acc, m1v[j], sd1v[j], a1v[j], r1v[j], outp[0], outp[1], outp[2], i2v[j]); // row n = 4(g-1) + j
             }
         }
     }
@@ -327,6 +308,15 @@ __global__ __launch_bounds__(256) void k_relayout(const float *__restrict__ src,
         if (r4) r4[c * ns + idx_r4(x, y, W)] = v;
         if (c4) c4[c * ns + idx_c4(x, y, H)] = v;
     }
+}
+
+// the same for the binary64 plane r1: R4 only
+__global__ __launch_bounds__(256) void k_relayout_f64(const double *__restrict__ src, int W, int H, double *__restrict__ r4) {
+    int px = blockIdx.x * blockDim.x + threadIdx.x;
+    if (px >= W * H) return;
+    int x = px % W, y = px / W;
+    size_t ns = (size_t)W * H;
+    for (int c = 0; c < 3; c++) r4[c * ns + idx_r4(x, y, W)] = src[c * ns + px];
 }
 
 } // namespace snes

@@ -39,12 +39,16 @@ struct CandMeta {
     int won;                           // number of won pixels
     unsigned char glist[kGroupsTotal + 2]; // per scale: ascending changed groups
     short gslot[kGroupsTotal];             // per scale: group -> slot, -1 if unchanged
+    unsigned char gcb[kGroupsTotal];       // per scale: group -> first 64-column block holding a won pixel (0 at scales narrower than 64)
 };
+constexpr int kColBuckets = 4; // 64-column blocks of the widest scale: work items are listed per (scale, first block)
+constexpr int kItemLists = kMaxScales * kColBuckets;
 
 struct SparseGeom {
     long long off_lin[kMaxScales], off_xybC[kMaxScales], off_xybR[kMaxScales], off_hout[kMaxScales]; // floats inside one candidate's storage
     long long cand_stride;
-    long long off_ckf[kMaxScales], off_cka[kMaxScales]; // checkpoint arrays of B
+    long long off_ckf[kMaxScales], off_cka[kMaxScales]; // checkpoint arrays of B (V pass)
+    long long off_ckh[kMaxScales];                      // B's H-pass state on entering column blocks 1.. of the wide scales: [3 ch][3][18][H]
     int goff[kMaxScales];                               // offset of scale s inside CandMeta::glist / gslot
 };
 
@@ -57,10 +61,11 @@ struct SparseParams {
     // --perceptual-palettes: the win test is CIEDE2000 (f32), too dear to repeat per stage: k_sparse_scan_lab evaluates it once
     // per contested pixel and records the won pixels in a per-candidate bitmap (W*H bits) that the other stages consult
     int perceptual; const float *labpx, *cand_lab; uint32_t *bitmap;
-    const float *img1C4, *img1R4, *mu1R4, *s11R4; // source arrays in the blocked layouts, + G.src_off[s]
+    const float *img1C4, *mu1R4, *sd1R4, *a1R4; const double *r1R4; // source arrays in the blocked layouts, + G.src_off[s] (maps_accumulate)
     float *store; CandMeta *meta;
-    unsigned int *items; int *item_count; long long item_stride; // per scale: items[s*item_stride + i] = cand*256 + slot*4 + ch
-    float *ckf; double *cka; double *part;
+    unsigned int *items; int *item_count; long long item_stride; // per (scale, first column block b): items[(s*4+b)*item_stride + i] = cand*256 + slot*4 + ch
+    float *ckf; double *cka; double *part; float *ckh;
+    int s_first; // the general H and V bodies skip scales below this one (the wide scales run the bodies of kernels_sparse2.hpp)
     int *first;       // per candidate: first changed group of scale 0 (H/4 if none), written by the scan for k_sparse_order
     const int *order; // k_sparse_v: candidates of the launch, longest column sweeps first (k_sparse_order); nullptr = as listed
 };
@@ -69,15 +74,108 @@ __device__ __forceinline__ uint32_t sparse_ci(uint32_t lo, uint32_t thr, uint32_
     return red_mean_key(crgb, lo & 0x00ffffffu) < thr ? ncol : (lo >> 24); // B passes crgb with thr ignored: see callers
 }
 
-__device__ __forceinline__ unsigned long long pair_or_compress(unsigned long long m);
 __device__ __forceinline__ uint32_t won_bit(const uint32_t *bm, int px) { return (bm[px >> 5] >> (px & 31)) & 1u; }
+
+__device__ __forceinline__ unsigned long long pair_or_compress(unsigned long long m) { // bit i of result = bit 2i | bit 2i+1 of m
+    m = (m | (m >> 1)) & 0x5555555555555555ull;
+    m = (m | (m >> 1)) & 0x3333333333333333ull;
+    m = (m | (m >> 2)) & 0x0f0f0f0f0f0f0f0full;
+    m = (m | (m >> 4)) & 0x00ff00ff00ff00ffull;
+    m = (m | (m >> 8)) & 0x0000ffff0000ffffull;
+    m = (m | (m >> 16)) & 0x00000000ffffffffull;
+    return m;
+}
+
+// ---- what a scan leaves behind for one candidate (shared by the RGB and the CIEDE2000 scans) ------------------------
+// Inputs, per wave = candidate: `mask` = changed 4-row groups of scale 0, `xmin`/`won` as in CandMeta, and in lane g the
+// smallest x of a won pixel inside group g of scale 0 (`xg`, >= W if none).  A scale has at most 64 groups, so its
+// changed set is one 64-bit word: scale s+1 is the pairwise OR of scale s, a group's slot is a popcount, its first
+// changed column the pairwise minimum.  Work items (candidate, slot, channel) are listed per scale and per first
+// 64-column block (the H pass of a changed row starts at that block, see sparse_h2_body); list space is claimed with one
+// returning atomic per block, scale and column block (a single counter word serialises at ~90 atomics/us, so one per
+// candidate would cost more than the scan itself); the block's NW waves take consecutive ranges.
+template <int NW>
+__device__ __forceinline__ void scan_publish(const SparseParams &P, const int k, const bool live, const unsigned long long mask, const int xmin, const int won, const int xg) {
+    constexpr int NL = kItemLists;
+    __shared__ int s_tot[NW][NL], s_off[NW][NL];
+    const Geom &G = P.G;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long below_mask = (1ull << lane) - 1ull;
+    unsigned long long ms[kMaxScales]; int cbs[kMaxScales];
+    {
+        unsigned long long m = live ? mask : 0ull;
+        int xgs = xg;
+#pragma unroll
+        for (int s = 0; s < kMaxScales; s++) {
+            ms[s] = 0ull; cbs[s] = 0;
+            if (s < G.nscales) {
+                const bool flag = ((m >> lane) & 1ull) != 0ull;
+                const int nb = G.sw[s] >= 64 ? (G.sw[s] >> 6) : 1;
+                // a changed input at column x moves the H outputs from column x - 4 on (the filter's right taps reach n + 4)
+                const int cb = (flag && nb > 1) ? min(max((xgs >> s) - 4, 0) >> 6, nb - 1) : 0;
+                ms[s] = m; cbs[s] = cb;
+#pragma unroll
+                for (int b = 0; b < kColBuckets; b++) {
+                    const unsigned long long mb = __ballot(flag && cb == b);
+                    if (lane == 0) s_tot[w][s * kColBuckets + b] = 3 * __popcll(mb);
+                }
+                m = pair_or_compress(m);
+                const int xa = __shfl(xgs, (2 * lane) & 63), xb = __shfl(xgs, (2 * lane + 1) & 63);
+                xgs = min(xa, xb); // lanes >= half the group count hold junk: their groups do not exist at the next scale
+            } else if (lane == 0) {
+#pragma unroll
+                for (int b = 0; b < kColBuckets; b++) s_tot[w][s * kColBuckets + b] = 0;
+            }
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NL) {
+        const int l = threadIdx.x;
+        int sum = 0;
+        for (int i = 0; i < NW; i++) { s_off[i][l] = sum; sum += s_tot[i][l]; }
+        const int base = sum ? atomicAdd(&P.item_count[l], sum) : 0;
+        for (int i = 0; i < NW; i++) s_off[i][l] += base;
+    }
+    __syncthreads();
+    if (!live) return;
+    CandMeta *M = P.meta + k;
+    if (lane == 0) { M->xmin = xmin; M->won = won; }
+#pragma unroll
+    for (int s = 0; s < kMaxScales; s++) {
+        if (s >= G.nscales) break;
+        const int NG = G.sh[s] >> 2;
+        const unsigned long long m = ms[s];
+        const int cb = cbs[s];
+        const bool flag = ((m >> lane) & 1ull) != 0ull;
+        const int below = __popcll(m & below_mask);
+        if (lane < NG) {
+            M->gslot[P.S.goff[s] + lane] = flag ? (short)below : (short)-1;
+            M->gcb[P.S.goff[s] + lane] = (unsigned char)cb;
+            if (flag) M->glist[P.S.goff[s] + below] = (unsigned char)lane;
+        }
+        if (lane == 0) M->ngroups[s] = __popcll(m);
+        if (lane == 0 && s == 0 && P.first) P.first[k] = m ? __ffsll((long long)m) - 1 : NG;
+#pragma unroll
+        for (int b = 0; b < kColBuckets; b++) {
+            const bool mine = flag && cb == b;
+            const unsigned long long mb = __ballot(mine);
+            if (mine) {
+                unsigned int *dst = P.items + (size_t)(s * kColBuckets + b) * P.item_stride + s_off[w][s * kColBuckets + b] + 3 * __popcll(mb & below_mask);
+                const unsigned int v = (unsigned int)k * 256u + (unsigned int)below * 4u;
+                dst[0] = v; dst[1] = v + 1u; dst[2] = v + 2u;
+            }
+        }
+    }
+}
 
 // ---- perceptual scan: CIEDE2000 win test per contested pixel, one wave per candidate ------------------------
 __device__ __forceinline__ void sparse_scan_lab_body(const SparseParams &P) {
     __shared__ uint32_t s_queue[4][128];
+    __shared__ int s_gx[4][64]; // per wave: smallest won x of every scale-0 group
     const Geom &G = P.G;
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
+    s_gx[w][lane] = 0x7fff;
     const int wi = (int)blockIdx.x * 4 + w;
     const bool live = wi < P.ncand;
     const int k = P.k0 + (live ? wi : 0);
@@ -89,6 +187,7 @@ __device__ __forceinline__ void sparse_scan_lab_body(const SparseParams &P) {
         auto take = [&](uint32_t px) { // the candidate wins pixel px
             const int x = (int)(px & (unsigned)(G.W - 1)), y = (int)(px / (unsigned)G.W);
             atomicOr(&bm[px >> 5], 1u << (px & 31));
+            atomicMin(&s_gx[w][y >> 2], x);
             mask |= 1ull << (y >> 2);
             xmin = min(xmin, x);
             won++;
@@ -132,39 +231,7 @@ __device__ __forceinline__ void sparse_scan_lab_body(const SparseParams &P) {
             won += __shfl_xor(won, o);
         }
     }
-    __shared__ int s_tot[4][kMaxScales], s_off[4][kMaxScales];
-    unsigned long long m = live ? mask : 0ull;
-    if (lane == 0) {
-        unsigned long long mm = m;
-        for (int s = 0; s < G.nscales; s++) { s_tot[w][s] = 3 * __popcll(mm); mm = pair_or_compress(mm); }
-    }
-    __syncthreads();
-    if (threadIdx.x < G.nscales) {
-        const int s = threadIdx.x;
-        int sum = 0;
-        for (int i = 0; i < 4; i++) { s_off[i][s] = sum; sum += s_tot[i][s]; }
-        const int base = sum ? atomicAdd(&P.item_count[s], sum) : 0;
-        for (int i = 0; i < 4; i++) s_off[i][s] += base;
-    }
-    __syncthreads();
-    if (!live) return;
-    CandMeta *M = P.meta + k;
-    if (lane == 0) { M->xmin = xmin; M->won = won; }
-    for (int s = 0; s < G.nscales; s++) {
-        const int NG = G.sh[s] >> 2;
-        const int total = __popcll(m);
-        if (lane < NG) {
-            const int flag = (int)((m >> lane) & 1ull);
-            const int below = __popcll(m & ((1ull << lane) - 1ull));
-            M->gslot[P.S.goff[s] + lane] = flag ? (short)below : (short)-1;
-            if (flag) M->glist[P.S.goff[s] + below] = (unsigned char)lane;
-        }
-        if (lane == 0) M->ngroups[s] = total;
-        if (lane == 0 && s == 0 && P.first) P.first[k] = m ? __ffsll((long long)m) - 1 : NG;
-        const int base = s_off[w][s];
-        for (int i = lane; i < total * 3; i += 64) P.items[(size_t)s * P.item_stride + base + i] = (unsigned int)k * 256u + (unsigned int)(i / 3) * 4u + (unsigned int)(i % 3);
-        m = pair_or_compress(m);
-    }
+    scan_publish<4>(P, k, live, mask, xmin, won, s_gx[w][lane]);
 }
 
 // ---- which groups does each candidate change? ---------------------------------------------------------
@@ -172,22 +239,15 @@ __device__ __forceinline__ void sparse_scan_lab_body(const SparseParams &P) {
 // contested pixels and keeps a 64-bit mask of the 4-row groups it saw change; the wave ORs the masks
 // (and min-reduces x) with shuffles.  A scale has at most 64 groups, so its changed set is one 64-bit
 // word: scale s+1 is the pairwise OR of scale s, a group's slot is a popcount.  No LDS, no barriers.
-__device__ __forceinline__ unsigned long long pair_or_compress(unsigned long long m) { // bit i of result = bit 2i | bit 2i+1 of m
-    m = (m | (m >> 1)) & 0x5555555555555555ull;
-    m = (m | (m >> 1)) & 0x3333333333333333ull;
-    m = (m | (m >> 2)) & 0x0f0f0f0f0f0f0f0full;
-    m = (m | (m >> 4)) & 0x00ff00ff00ff00ffull;
-    m = (m | (m >> 8)) & 0x0000ffff0000ffffull;
-    m = (m | (m >> 16)) & 0x00000000ffffffffull;
-    return m;
-}
 constexpr int kScanTile = 6144; // contested pixels staged in LDS per pass (the BASELINE slot has ~6.8 k)
 __device__ __forceinline__ void sparse_scan_body(const SparseParams &P) {
     // 16 waves = 16 candidates per block share one LDS copy of the slot's contested-pixel list
     __shared__ uint32_t s_rgb[kScanTile], s_thr[kScanTile];
     __shared__ unsigned short s_px[kScanTile]; // x | (y>>2) << 8 would lose x precision: keep x (8 bit) and group (6 bit)
+    __shared__ int s_gx[16][64]; // per wave: smallest won x of every scale-0 group
     const Geom &G = P.G;
     const int lane = threadIdx.x & 63;
+    s_gx[threadIdx.x >> 6][lane] = 0x7fff;
     const int wi = (int)blockIdx.x * 16 + (threadIdx.x >> 6);
     const bool live = P.is_base ? (wi == 0) : (wi < P.ncand);
     const int k = P.is_base ? P.base : P.k0 + (live ? wi : 0);
@@ -209,6 +269,7 @@ __device__ __forceinline__ void sparse_scan_body(const SparseParams &P) {
                 for (int i = lane; i < nt; i += 64) {
                     if (red_mean_key(crgb, s_rgb[i]) < s_thr[i]) {
                         const int px = s_px[i];
+                        atomicMin(&s_gx[threadIdx.x >> 6][px >> 8], px & 255);
                         mask |= 1ull << (px >> 8);
                         xmin = min(xmin, px & 255);
                         won++;
@@ -223,42 +284,7 @@ __device__ __forceinline__ void sparse_scan_body(const SparseParams &P) {
             won += __shfl_xor(won, o);
         }
     }
-    // Work-item slots: one returning atomic per block and scale (a single counter word serialises at ~90 atomics/us,
-    // so one per candidate would cost more than the scan itself); the block's 16 waves take consecutive ranges.
-    __shared__ int s_tot[16][kMaxScales], s_off[16][kMaxScales];
-    const int w = threadIdx.x >> 6;
-    unsigned long long m = live ? mask : 0ull;
-    if (lane == 0) {
-        unsigned long long mm = m;
-        for (int s = 0; s < G.nscales; s++) { s_tot[w][s] = 3 * __popcll(mm); mm = pair_or_compress(mm); }
-    }
-    __syncthreads();
-    if (threadIdx.x < G.nscales) {
-        const int s = threadIdx.x;
-        int sum = 0;
-        for (int i = 0; i < 16; i++) { s_off[i][s] = sum; sum += s_tot[i][s]; }
-        const int base = sum ? atomicAdd(&P.item_count[s], sum) : 0;
-        for (int i = 0; i < 16; i++) s_off[i][s] += base;
-    }
-    __syncthreads();
-    if (!live) return;
-    CandMeta *M = P.meta + k;
-    if (lane == 0) { M->xmin = xmin; M->won = won; }
-    for (int s = 0; s < G.nscales; s++) {
-        const int NG = G.sh[s] >> 2;
-        const int total = __popcll(m);
-        if (lane < NG) {
-            const int flag = (int)((m >> lane) & 1ull);
-            const int below = __popcll(m & ((1ull << lane) - 1ull));
-            M->gslot[P.S.goff[s] + lane] = flag ? (short)below : (short)-1;
-            if (flag) M->glist[P.S.goff[s] + below] = (unsigned char)lane;
-        }
-        if (lane == 0) M->ngroups[s] = total;
-        if (lane == 0 && s == 0 && P.first) P.first[k] = m ? __ffsll((long long)m) - 1 : NG;
-        const int base = s_off[w][s];
-        for (int i = lane; i < total * 3; i += 64) P.items[(size_t)s * P.item_stride + base + i] = (unsigned int)k * 256u + (unsigned int)(i / 3) * 4u + (unsigned int)(i % 3);
-        m = pair_or_compress(m);
-    }
+    scan_publish<16>(P, k, live, mask, xmin, won, P.is_base ? 0 : s_gx[threadIdx.x >> 6][lane]);
 }
 
 // ---- downscale chain + XYB on changed groups only -------------------------------------------------------
@@ -421,10 +447,10 @@ __device__ __forceinline__ void sparse_h_body(const SparseParams &P) {
     __shared__ float s_lut[3][256];
     __shared__ float s_tr[3][64 * 5];
     const Geom &G = P.G;
-    const int s = blockIdx.y;
-    if (s >= G.nscales) return;
+    const int list = blockIdx.y, s = list / kColBuckets; // one item list per (scale, first column block)
+    if (s >= G.nscales || s < P.s_first) return;
     const int lane = threadIdx.x;
-    const int count = P.item_count[s];
+    const int count = P.item_count[list];
     if ((int)blockIdx.x * 16 >= count) return;
     const bool S0 = (s == 0);
     if (S0) {
@@ -434,7 +460,7 @@ __device__ __forceinline__ void sparse_h_body(const SparseParams &P) {
     for (int i0 = blockIdx.x * 16; i0 < count; i0 += gridDim.x * 16) { // grid-stride over item quads: no empty waves
     const int qi = i0 + (lane >> 2);
     const bool valid = qi < count;
-    const unsigned int it = P.items[(size_t)s * P.item_stride + (valid ? qi : i0)];
+    const unsigned int it = P.items[(size_t)list * P.item_stride + (valid ? qi : i0)];
     const int k = (int)(it >> 8), j = (int)((it >> 2) & 63u), ch = (int)(it & 3u);
     const bool is_base = (k == P.base);
     const CandMeta *M = P.meta + k;
@@ -599,9 +625,10 @@ __device__ __forceinline__ void sparse_v_body(const SparseParams &P, const int s
     const float4 *hm = reinterpret_cast<const float4 *>(mine + P.S.off_hout[s]) + (size_t)(ch * 3) * W + hx;   // + slot*9W
     const float4 *xb = S0 ? nullptr : reinterpret_cast<const float4 *>(basep + P.S.off_xybR[s]) + (size_t)ch * W + x; // + g*3W
     const float4 *xm = S0 ? nullptr : reinterpret_cast<const float4 *>(mine + P.S.off_xybR[s]) + (size_t)ch * W + x;
-    const float4 *img1 = reinterpret_cast<const float4 *>(P.img1R4 + G.src_off[s] + (size_t)ch * ns) + x; // + g*W
-    const float4 *mu1 = reinterpret_cast<const float4 *>(P.mu1R4 + G.src_off[s] + (size_t)ch * ns) + x;
-    const float4 *s11 = reinterpret_cast<const float4 *>(P.s11R4 + G.src_off[s] + (size_t)ch * ns) + x;
+    const float4 *mu1 = reinterpret_cast<const float4 *>(P.mu1R4 + G.src_off[s] + (size_t)ch * ns) + x; // + g*W
+    const float4 *sd1 = reinterpret_cast<const float4 *>(P.sd1R4 + G.src_off[s] + (size_t)ch * ns) + x;
+    const float4 *a1 = reinterpret_cast<const float4 *>(P.a1R4 + G.src_off[s] + (size_t)ch * ns) + x;
+    const double2 *r1 = reinterpret_cast<const double2 *>(P.r1R4 + G.src_off[s] + (size_t)ch * ns) + 2 * (size_t)x; // + g*2W
     const uint4 *pk = S0 ? reinterpret_cast<const uint4 *>(P.packR4) + 2 * (size_t)x : nullptr; // + g*2W
     // checkpoints: ckf[s][ch][g][18][W], cka[s][ch][g][6][W]
     float *ckf = P.ckf + P.S.off_ckf[s] + (size_t)ch * (H4 + 2) * 18 * W + x;
@@ -656,10 +683,12 @@ __device__ __forceinline__ void sparse_v_body(const SparseParams &P, const int s
     }
     // running pointers of the map inputs of row group g-1 (valid from g = 1 on)
     const int gm0 = gs >= 1 ? gs - 1 : 0;
-    const float4 *p_i1 = img1 + (uint32_t)__mul24(gm0, W), *p_m1 = mu1 + (uint32_t)__mul24(gm0, W), *p_s11 = s11 + (uint32_t)__mul24(gm0, W);
+    const float4 *p_m1 = mu1 + (uint32_t)__mul24(gm0, W), *p_sd1 = sd1 + (uint32_t)__mul24(gm0, W), *p_a1 = a1 + (uint32_t)__mul24(gm0, W);
+    const double2 *p_r1 = r1 + 2u * (uint32_t)__mul24(gm0, W);
     const uint4 *p_pk = S0 ? pk + 2u * (uint32_t)__mul24(gm0, W) : nullptr;
     const uint32_t *bm = (S0 && P.perceptual && !is_base) ? P.bitmap + (size_t)k * (G.W * G.H / 32) : nullptr;
-    float4 n_i1 = zero4, n_m1 = zero4, n_s11 = zero4, n_x = zero4; // BM == 1 only
+    float4 n_m1 = zero4, n_sd1 = zero4, n_a1 = zero4, n_x = zero4; // BM == 1 only
+    double2 n_ra = make_double2(1.0, 1.0), n_rb = n_ra;
     uint4 n_pa = make_uint4(0, 0, 0, 0), n_pb = n_pa;
     float *ck_f = BM == 1 ? ckf + (size_t)gs * 18 * W : nullptr; // B only: running pointers of the record being written
     double *ck_a = BM == 1 ? cka + (size_t)gs * 6 * W : nullptr;
@@ -685,19 +714,20 @@ __device__ __forceinline__ void sparse_v_body(const SparseParams &P, const int s
         if (g + 1 < H4) { const float4 *hp = hgroup(g + 1); NXT[0] = hp[0]; NXT[1] = hp[W]; NXT[2] = hp[2 * W]; }             \
         else { NXT[0] = zero4; NXT[1] = zero4; NXT[2] = zero4; }                                                              \
         /* inputs of the maps of row group g-1, consumed after the recurrence steps below */                                  \
-        float4 c_i1 = zero4, c_m1 = zero4, c_s11 = zero4, c_x = zero4;                                                        \
+        float4 c_m1 = zero4, c_sd1 = zero4, c_a1 = zero4, c_x = zero4;                                                        \
+        double2 c_ra = make_double2(1.0, 1.0), c_rb = c_ra;                                                                   \
         uint4 c_pa = make_uint4(0, 0, 0, 0), c_pb = c_pa;                                                                     \
         if (BM == 1) { /* B (single image, registers to spare): fetched one iteration ahead, group g now for iteration g+1 */  \
-            c_i1 = n_i1; c_m1 = n_m1; c_s11 = n_s11; c_x = n_x; c_pa = n_pa; c_pb = n_pb;                                      \
+            c_m1 = n_m1; c_sd1 = n_sd1; c_a1 = n_a1; c_ra = n_ra; c_rb = n_rb; c_x = n_x; c_pa = n_pa; c_pb = n_pb;            \
             if (g < H4) {                                                                                                     \
-                n_i1 = *p_i1; n_m1 = *p_m1; n_s11 = *p_s11;                                                                   \
-                p_i1 += W; p_m1 += W; p_s11 += W;                                                                             \
+                n_m1 = *p_m1; n_sd1 = *p_sd1; n_a1 = *p_a1; n_ra = p_r1[0]; n_rb = p_r1[1];                                   \
+                p_m1 += W; p_sd1 += W; p_a1 += W; p_r1 += 2 * W;                                                              \
                 if (S0) { n_pa = p_pk[0]; n_pb = p_pk[1]; p_pk += 2 * W; }                                                    \
                 else n_x = xb[(uint32_t)__mul24(g, W3)];                                                                      \
             }                                                                                                                 \
         } else if (g >= 1) {                                                                                                  \
-            c_i1 = *p_i1; c_m1 = *p_m1; c_s11 = *p_s11;                                                                       \
-            p_i1 += W; p_m1 += W; p_s11 += W;                                                                                 \
+            c_m1 = *p_m1; c_sd1 = *p_sd1; c_a1 = *p_a1; c_ra = p_r1[0]; c_rb = p_r1[1];                                       \
+            p_m1 += W; p_sd1 += W; p_a1 += W; p_r1 += 2 * W;                                                                  \
             if (S0) { c_pa = p_pk[0]; c_pb = p_pk[1]; p_pk += 2 * W; }                                                        \
             else { const int sl = SNES_GSLOT(g - 1); c_x = sl >= 0 ? xm[(uint32_t)__mul24(sl, W3)] : xb[(uint32_t)__mul24(g - 1, W3)]; } \
         }                                                                                                                     \
@@ -728,30 +758,10 @@ __device__ __forceinline__ void sparse_v_body(const SparseParams &P, const int s
                 i2v[0] = c0 == (uint32_t)P.ncol ? cand_v : s_lut[c0]; i2v[1] = c1 == (uint32_t)P.ncol ? cand_v : s_lut[c1];   \
                 i2v[2] = c2 == (uint32_t)P.ncol ? cand_v : s_lut[c2]; i2v[3] = c3 == (uint32_t)P.ncol ? cand_v : s_lut[c3];   \
             }                                                                                                                 \
-            const float i1v[4] = {c_i1.x, c_i1.y, c_i1.z, c_i1.w}, m1v[4] = {c_m1.x, c_m1.y, c_m1.z, c_m1.w}, s11v[4] = {c_s11.x, c_s11.y, c_s11.z, c_s11.w}; \
-            _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                                   \
-                const float m1 = m1v[q], m2 = outp[0][q], v11 = s11v[q], v22 = outp[1][q], v12 = outp[2][q];                  \
-                const float i1 = i1v[q], i2 = i2v[q];                                                                         \
-                const float mu11 = m1 * m1, mu22 = m2 * m2, mu12 = m1 * m2;                                                   \
-                const float mu_diff = m1 - m2;                                                                                \
-                const float num_m = fmaf(mu_diff, -mu_diff, 1.0f);                                                            \
-                const float num_s = fmaf(2.0f, v12 - mu12, 0.0009f);                                                          \
-                const float denom_s = (v11 - mu11) + (v22 - mu22) + 0.0009f;                                                  \
-                double d = 1.0 - (double)((num_m * num_s) / denom_s);                                                         \
-                d = d > 0.0 ? d : 0.0;                                                                                        \
-                acc[0] += d;                                                                                                  \
-                const double dd = d * d;                                                                                      \
-                acc[1] += dd * dd;                                                                                            \
-                const double d1 = (1.0 + (double)fabsf(i2 - m2)) / (1.0 + (double)fabsf(i1 - m1)) - 1.0;                      \
-                const double art = d1 > 0.0 ? d1 : 0.0;                                                                       \
-                const double det = (-d1) > 0.0 ? (-d1) : 0.0;                                                                 \
-                acc[2] += art;                                                                                                \
-                const double a2 = art * art;                                                                                  \
-                acc[3] += a2 * a2;                                                                                            \
-                acc[4] += det;                                                                                                \
-                const double l2 = det * det;                                                                                  \
-                acc[5] += l2 * l2;                                                                                            \
-            }                                                                                                                 \
+            const float m1v[4] = {c_m1.x, c_m1.y, c_m1.z, c_m1.w}, sd1v[4] = {c_sd1.x, c_sd1.y, c_sd1.z, c_sd1.w}, a1v[4] = {c_a1.x, c_a1.y, c_a1.z, c_a1.w}; \
+            const double r1v[4] = {c_ra.x, c_ra.y, c_rb.x, c_rb.y};                                                           \
+            _Pragma("unroll") for (int q = 0; q < 4; q++)                                                                     \
+                maps_accumulate(acc, m1v[q], sd1v[q], a1v[q], r1v[q], outp[0][q], outp[1][q], outp[2][q], i2v[q]);            \
         }                                                                                                                     \
     }
     for (int g0 = gs; g0 <= H4; g0 += 6) {
@@ -783,7 +793,7 @@ __device__ __forceinline__ void sparse_v_body(const SparseParams &P, const int s
     }
 }
 // candidates: every scale in one launch, flags decided at run time (see sparse_v_body)
-__global__ __launch_bounds__(256, 4) void k_sparse_v(SparseParams P) { sparse_v_body<false, 2, 2>(P, (int)blockIdx.y); }
+__global__ __launch_bounds__(256, 4) void k_sparse_v(SparseParams P) { if ((int)blockIdx.y >= P.s_first) sparse_v_body<false, 2, 2>(P, (int)blockIdx.y); }
 // B: one launch as well, each scale in its specialised flavour
 __device__ __forceinline__ void sparse_v_base_body(const SparseParams &P) {
     const int s = (int)blockIdx.y;

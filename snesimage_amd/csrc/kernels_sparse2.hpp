@@ -1,0 +1,340 @@
+// snesimage_amd/csrc/kernels_sparse2.hpp — the group-sparse H and V passes for the scales at least 64 pixels wide
+// (256, 128 and 64 at the BASELINE size: 98.4 % of the pyramid's pixels).  kernels_sparse.hpp explains the method and keeps
+// the general bodies, which still serve the narrow scales and the base image's V pass; the bodies here compute the same
+// values operation for operation and differ in how the work is cut and how the data moves:
+//
+//   * A changed row is recomputed from the 64-column block that holds its first changed input, not from column 0.
+//     The recurrence is causal along x, so its state on entering column block b is B's as long as nothing left of the
+//     block differs: B's H pass leaves that state behind (18 floats per row, channel and block boundary: `ckh`), the
+//     scan lists the work items per (scale, first block), and every wave of sparse_h2_body starts all its rows at the
+//     same block.  On the BASELINE workload this removes ~40 % of the H pass's steps and of its output traffic.
+//   * H output leaves a wave as 256-byte runs (16 columns x 4 rows of one plane, staged through LDS) instead of the
+//     64-byte runs one column quad gives: every store instruction writes whole 128-byte lines.
+//   * At scale 0 the H pass also stores the XYB value it looked up for every pixel of a changed group (and B's H pass
+//     does for the whole of B), so the V pass reads its map input `img2` from a plane at every scale: it no longer
+//     touches the pack, the palette table or the won-pixel bitmap, and has one body for all scales.
+//   * In sparse_v2_body a wave's 64 columns belong to one (candidate, channel), so the first changed group, the loop
+//     counter and the group -> storage choice are wave-uniform: base addresses live in SGPRs and every lane adds a
+//     32-bit byte offset (global loads in their scalar-base form) — the 64-bit per-lane address arithmetic and the
+//     pointer selects of the general body were a fifth of its instructions and the source of its register spills.
+//     A wave reads a changed group from the candidate's own storage only if the group's first block is not to the
+//     right of the wave's columns; otherwise the candidate's H pass has not written those columns and they are B's.
+#pragma once
+#include "kernels_sparse.hpp"
+
+namespace snes {
+
+// recurrence steps, identical to kernels_fast.hpp / kernels_sparse.hpp
+#define SNES_HSTEP(SUM, A, B, OUT)                                                   \
+    {                                                                                \
+        float o1_ = (SUM) * n2_0, o3_ = (SUM) * n2_1, o5_ = (SUM) * n2_2;            \
+        o1_ = fmaf(-1.0f, B[0], o1_); o3_ = fmaf(-1.0f, B[1], o3_); o5_ = fmaf(-1.0f, B[2], o5_); \
+        o1_ = fmaf(mp_0, A[0], o1_); o3_ = fmaf(mp_1, A[1], o3_); o5_ = fmaf(mp_2, A[2], o5_);    \
+        B[0] = o1_; B[1] = o3_; B[2] = o5_;                                          \
+        OUT = o1_ + o3_ + o5_;                                                       \
+    }
+#define SNES_VSTEP(SUM, A, B, OUT)                                                   \
+    {                                                                                \
+        float o1_ = fmaf(A[0], d1_0, B[0]), o3_ = fmaf(A[1], d1_1, B[1]), o5_ = fmaf(A[2], d1_2, B[2]); \
+        o1_ = fmaf((SUM), n2_0, -o1_); o3_ = fmaf((SUM), n2_1, -o3_); o5_ = fmaf((SUM), n2_2, -o5_);    \
+        B[0] = o1_; B[1] = o3_; B[2] = o5_;                                          \
+        OUT = o1_ + o3_ + o5_;                                                       \
+    }
+
+// ---- H pass of changed groups, from their first changed column block -----------------------------------------------------
+// grid.y = item list (scale * kColBuckets + first block); block = one wave = 16 work items (candidate, slot, channel), a
+// lane quad = the four rows of an item.  Column quads g run from 16*block to W/4; iteration g consumes the inputs of quad g
+// (the "right" taps in[n+4]) and yields the outputs of quad g-1; the five-slot register ring keeps quads g-3..g+1.
+// S0: scale 0 — the candidate's pixels come from the pack (win test) instead of an XYB plane.
+template <bool S0>
+__device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int list) {
+    constexpr int NP = S0 ? 4 : 3;        // staged planes: the three H outputs (+ the XYB input at scale 0)
+    constexpr int ISTR = NP * 64 + 4;     // staging words per item; the pad spreads the quads' rows over the LDS banks
+    __shared__ float s_lut[S0 ? 3 * 256 : 1];
+    __shared__ __attribute__((aligned(16))) float s_out[16 * ISTR];
+    __shared__ long long s_hbase[16], s_xbase[16]; // per item: float offset of its H output / XYB planes inside P.store, -1 = no item
+    const Geom &G = P.G;
+    const int s = list / kColBuckets, cb = list % kColBuckets;
+    const int W = G.sw[s], H = G.sh[s];
+    const int lane = threadIdx.x;
+    const int count = P.item_count[list];
+    if ((int)blockIdx.x * 16 >= count) return;
+    if (S0) {
+        for (int i = lane; i < 3 * 256; i += 64) { const int c = i >> 8, j = i & 255; s_lut[i] = (j < P.ncol + 2) ? P.pal_xyb[3 * j + c] : 0.0f; }
+        __syncthreads();
+    }
+    const float n2_0 = P.K.n2[0], n2_1 = P.K.n2[1], n2_2 = P.K.n2[2];
+    const float mp_0 = -P.K.d1[0], mp_1 = -P.K.d1[1], mp_2 = -P.K.d1[2];
+    const int G4 = W >> 2, gs = cb << 4, gstart = gs >= 3 ? gs - 3 : 0; // three warm-up iterations refill the ring
+    const int r = lane & 3;
+    for (int i0 = blockIdx.x * 16; i0 < count; i0 += gridDim.x * 16) { // grid-stride over item quads
+        const int qi = i0 + (lane >> 2);
+        const bool valid = qi < count;
+        const unsigned int it = P.items[(size_t)list * P.item_stride + (valid ? qi : i0)];
+        const int k = (int)(it >> 8), j = (int)((it >> 2) & 63u), ch = (int)(it & 3u);
+        const bool is_base = (k == P.base);
+        const CandMeta *M = P.meta + k;
+        const int y = 4 * (int)M->glist[P.S.goff[s] + j] + r;
+        const size_t ns = (size_t)W * H;
+        const float cand_v = (S0 && !is_base) ? P.cand_tab[8 * (size_t)k + 3 + ch] : 0.0f;
+        const uint32_t crgb = (S0 && !is_base) ? __float_as_uint(P.cand_tab[8 * (size_t)k + 6]) : 0u;
+        const uint32_t never = is_base ? 0u : 0xffffffffu; // thr & never == 0 for B: it wins nothing
+        const float4 *in1 = reinterpret_cast<const float4 *>(P.img1C4 + G.src_off[s] + (size_t)ch * ns) + y;   // C4: + g*H
+        const uint4 *pk = S0 ? reinterpret_cast<const uint4 *>(P.packC4) + 2 * (size_t)y : nullptr;            // + g*2H
+        const float4 *in2 = S0 ? nullptr
+                               : reinterpret_cast<const float4 *>(P.store + (size_t)k * P.S.cand_stride + P.S.off_xybC[s] + (size_t)j * 12 * W + (size_t)ch * 4 * W) + r; // + g*4
+        __syncthreads(); // the previous round's flush has read the bases
+        if (r == 0) {
+            s_hbase[lane >> 2] = valid ? (long long)k * P.S.cand_stride + P.S.off_hout[s] + (long long)j * 36 * W + (long long)(ch * 3) * 4 * W : -1ll;
+            s_xbase[lane >> 2] = (long long)k * P.S.cand_stride + P.S.off_xybR[s] + (long long)j * 12 * W + (long long)ch * 4 * W;
+        }
+        float sa[3][3], sb[3][3];
+        // B's state on entering the block: ckh[s][ch][block-1][18][row]
+        const float *ck = P.ckh + P.S.off_ckh[s] + ((size_t)(ch * 3 + (cb > 0 ? cb - 1 : 0)) * 18) * H + y;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                sa[p][q] = gs > 0 ? ck[(size_t)(p * 6 + q) * H] : 0.0f;
+                sb[p][q] = gs > 0 ? ck[(size_t)(p * 6 + 3 + q) * H] : 0.0f;
+            }
+        float4 r1[5], r2[5];
+#pragma unroll
+        for (int a = 0; a < 5; a++) { r1[a] = make_float4(0.f, 0.f, 0.f, 0.f); r2[a] = r1[a]; }
+        uint4 n_pa = make_uint4(0, 0, 0, 0), n_pb = n_pa;
+        r1[0] = in1[(size_t)gstart * H];
+        if (S0) { n_pa = pk[(size_t)gstart * H * 2]; n_pb = pk[(size_t)gstart * H * 2 + 1]; } else r2[0] = in2[(size_t)gstart * 4];
+        for (int g0 = gstart; g0 <= G4; g0 += 5) {
+#pragma unroll
+            for (int u = 0; u < 5; u++) {
+                const int g = g0 + u;
+                if (g > G4) break;
+                const int un = (u + 1) % 5, ua = (u + 2) % 5, ub = (u + 3) % 5, ul = (u + 4) % 5; // slots of quads g+1, g-3, g-2, g-1
+                const uint4 c_pa = n_pa, c_pb = n_pb;
+                if (g + 1 < G4) {
+                    r1[un] = in1[(size_t)(g + 1) * H];
+                    if (S0) { n_pa = pk[(size_t)(g + 1) * H * 2]; n_pb = pk[(size_t)(g + 1) * H * 2 + 1]; } else r2[un] = in2[(size_t)(g + 1) * 4];
+                } else { r1[un] = make_float4(0.f, 0.f, 0.f, 0.f); r2[un] = r1[un]; n_pa = make_uint4(0, 0, 0, 0); n_pb = n_pa; }
+                if (S0 && g < G4) {
+                    uint32_t c0, c1, c2, c3;
+                    if (P.perceptual && !is_base) { // four consecutive pixels of row y: four consecutive bits of one bitmap word
+                        const int px0 = y * W + (g << 2);
+                        const uint32_t b4 = (P.bitmap[(size_t)k * (G.W * G.H / 32) + (px0 >> 5)] >> (px0 & 31)) & 0xfu;
+                        c0 = (b4 & 1u) ? (uint32_t)P.ncol : (c_pa.x >> 24); c1 = (b4 & 2u) ? (uint32_t)P.ncol : (c_pa.z >> 24);
+                        c2 = (b4 & 4u) ? (uint32_t)P.ncol : (c_pb.x >> 24); c3 = (b4 & 8u) ? (uint32_t)P.ncol : (c_pb.z >> 24);
+                    } else {
+                        c0 = sparse_ci(c_pa.x, c_pa.y & never, crgb, (uint32_t)P.ncol); c1 = sparse_ci(c_pa.z, c_pa.w & never, crgb, (uint32_t)P.ncol);
+                        c2 = sparse_ci(c_pb.x, c_pb.y & never, crgb, (uint32_t)P.ncol); c3 = sparse_ci(c_pb.z, c_pb.w & never, crgb, (uint32_t)P.ncol);
+                    }
+                    const float *lut = s_lut + (ch << 8);
+                    r2[u].x = c0 == (uint32_t)P.ncol ? cand_v : lut[c0]; r2[u].y = c1 == (uint32_t)P.ncol ? cand_v : lut[c1];
+                    r2[u].z = c2 == (uint32_t)P.ncol ? cand_v : lut[c2]; r2[u].w = c3 == (uint32_t)P.ncol ? cand_v : lut[c3];
+                }
+                if (g < gs) continue; // warm-up: the ring fills, the state is B's checkpoint
+                if (P.is_base && g > 0 && (g & 15) == 0 && g < G4 && valid) { // B: the state on entering block g/16
+                    float *co = P.ckh + P.S.off_ckh[s] + ((size_t)(ch * 3 + (g >> 4) - 1) * 18) * H + y;
+#pragma unroll
+                    for (int p = 0; p < 3; p++)
+#pragma unroll
+                        for (int q = 0; q < 3; q++) { co[(size_t)(p * 6 + q) * H] = sa[p][q]; co[(size_t)(p * 6 + 3 + q) * H] = sb[p][q]; }
+                }
+                const float v1[4] = {r1[u].x, r1[u].y, r1[u].z, r1[u].w}, v2[4] = {r2[u].x, r2[u].y, r2[u].z, r2[u].w};
+                const float l1[4] = {r1[ua].z, r1[ua].w, r1[ub].x, r1[ub].y}, l2[4] = {r2[ua].z, r2[ua].w, r2[ub].x, r2[ub].y};
+                float outp[3][4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float s0 = l2[q] + v2[q];
+                    const float s1 = (l2[q] * l2[q]) + (v2[q] * v2[q]);
+                    const float s2 = (l1[q] * l2[q]) + (v1[q] * v2[q]);
+                    if ((q & 1) == 0) { SNES_HSTEP(s0, sa[0], sb[0], outp[0][q]) SNES_HSTEP(s1, sa[1], sb[1], outp[1][q]) SNES_HSTEP(s2, sa[2], sb[2], outp[2][q]) }
+                    else { SNES_HSTEP(s0, sb[0], sa[0], outp[0][q]) SNES_HSTEP(s1, sb[1], sa[1], outp[1][q]) SNES_HSTEP(s2, sb[2], sa[2], outp[2][q]) }
+                }
+                if (g > gs) { // outputs of quad g-1 (those of quad gs-1 are B's and stay unwritten): stage [plane][column % 16][row]
+                    float *so = s_out + (lane >> 2) * ISTR + (((g - 1) & 3) << 4) + r;
+#pragma unroll
+                    for (int p = 0; p < 3; p++) { so[p * 64 + 0] = outp[p][0]; so[p * 64 + 4] = outp[p][1]; so[p * 64 + 8] = outp[p][2]; so[p * 64 + 12] = outp[p][3]; }
+                    if (S0) { so[3 * 64 + 0] = r2[ul].x; so[3 * 64 + 4] = r2[ul].y; so[3 * 64 + 8] = r2[ul].z; so[3 * 64 + 12] = r2[ul].w; }
+                    if ((g & 3) == 0) { // 16 columns complete: 256-byte runs, 16 bytes per lane
+                        __syncthreads();
+                        const int x0 = (g - 4) << 2; // first column of the run
+                        const long long o_h = ((long long)(x0 >> 6) << 8) + ((x0 & 63) << 2), o_x = (long long)x0 << 2;
+#pragma unroll
+                        for (int m = 0; m < NP * 4; m++) {
+                            const int idx = m * 64 + lane;
+                            const int item = idx / (NP * 16), rem = idx - item * (NP * 16), p = rem >> 4, c = rem & 15;
+                            const long long hb = s_hbase[item];
+                            if (hb >= 0) {
+                                const float4 v = *reinterpret_cast<const float4 *>(s_out + item * ISTR + p * 64 + c * 4);
+                                float *dst = (S0 && p == 3) ? P.store + s_xbase[item] + o_x + c * 4 : P.store + hb + (long long)p * 4 * W + o_h + c * 4;
+                                *reinterpret_cast<float4 *>(dst) = v;
+                            }
+                        }
+                        __syncthreads();
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- V pass + maps of one (candidate, channel) per 64-column wave, resumed from B's checkpoint ------------------------------
+// Same checkpoint records, tail ring and pooling as sparse_v_body (kernels_sparse.hpp); W >= 64 only.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T> __device__ __forceinline__ T ld_at(const void *sbase, uint32_t voff) { return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(sbase) + voff); }
+
+__device__ __forceinline__ void sparse_v2_body(const SparseParams &P, const int s) {
+    __shared__ short s_slot[4][64]; // per wave: group -> slot in the candidate's storage, -1 = B's group
+    // tails: xy halves two deep, zw halves three deep, [slot][plane][thread]; the pooling reduction reuses the space
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[(2 + 3) * 3 * 256 * sizeof(float2)];
+    double (*red)[6] = reinterpret_cast<double (*)[6]>(s_raw);
+    static_assert(sizeof(s_raw) >= 256 * 6 * sizeof(double), "reduction scratch must fit the tail ring");
+    const Geom &G = P.G;
+    const int W = G.sw[s], H = G.sh[s], H4 = H >> 2;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = uni(t >> 6);
+    const int wpp = W >> 6, ppw = 4 / wpp; // waves per pair, pairs per block
+    const int npairs = P.ncand * 3;
+    if ((int)blockIdx.x * ppw >= npairs) return;
+    const int ql = wv / wpp, xw = (wv - ql * wpp) << 6; // pair of the wave inside the block, first column of the wave
+    const int pair_raw = blockIdx.x * ppw + ql;
+    const bool active = pair_raw < npairs;
+    const int pair = active ? pair_raw : 0;
+    const int k = uni(P.k0 + (P.order ? P.order[pair / 3] : pair / 3)), ch = pair % 3;
+    const int x = xw + lane;
+    const CandMeta *M = P.meta + k;
+    { // effective slot of every group for this wave: the candidate's own rows only where its H pass has written this wave's columns
+        const int g = lane;
+        short sl = -1;
+        if (g < H4) { sl = M->gslot[P.S.goff[s] + g]; if (sl >= 0 && ((int)M->gcb[P.S.goff[s] + g] << 6) > xw) sl = -1; }
+        s_slot[wv][lane] = sl;
+    }
+    const int ng = uni(M->ngroups[s]);
+    const int cmin = uni((M->xmin >> s) - 5); // columns <= cmin see only unchanged inputs
+    const bool skip = ng == 0 || x <= cmin;
+    const int gs = uni(__all(skip) ? H4 + 1 : (int)M->glist[P.S.goff[s]]); // a skipping wave takes B's final sums
+    __syncthreads();
+
+    const size_t ns = (size_t)W * H;
+    const float *store_k = P.store + (size_t)k * P.S.cand_stride, *store_b = P.store + (size_t)P.base * P.S.cand_stride;
+    // wave-uniform bases; per group: + g * (36 W | 12 W | 4 W) floats
+    const float *h_own = store_k + P.S.off_hout[s] + (size_t)(ch * 3) * 4 * W + ((size_t)(xw >> 6) << 8);
+    const float *h_b = store_b + P.S.off_hout[s] + (size_t)(ch * 3) * 4 * W + ((size_t)(xw >> 6) << 8);
+    const float *x_own = store_k + P.S.off_xybR[s] + (size_t)ch * 4 * W + (size_t)xw * 4;
+    const float *x_b = store_b + P.S.off_xybR[s] + (size_t)ch * 4 * W + (size_t)xw * 4;
+    const float *m1_b = P.mu1R4 + G.src_off[s] + (size_t)ch * ns + (size_t)xw * 4;
+    const float *sd1_b = P.sd1R4 + G.src_off[s] + (size_t)ch * ns + (size_t)xw * 4;
+    const float *a1_b = P.a1R4 + G.src_off[s] + (size_t)ch * ns + (size_t)xw * 4;
+    const double *r1_b = P.r1R4 + G.src_off[s] + (size_t)ch * ns + (size_t)xw * 4;
+    const uint32_t l4 = (uint32_t)lane << 2, l8 = (uint32_t)lane << 3, l16 = (uint32_t)lane << 4, l32 = (uint32_t)lane << 5;
+    const uint32_t W4 = (uint32_t)W * 4u; // floats per (plane, group)
+
+    const float n2_0 = P.K.n2[0], n2_1 = P.K.n2[1], n2_2 = P.K.n2[2];
+    const float d1_0 = P.K.d1[0], d1_1 = P.K.d1[1], d1_2 = P.K.d1[2];
+    float sa[3][3], sb[3][3];
+    double acc[6];
+    { // checkpoint record gs: ckf[s][ch][g][18][W], cka[s][ch][g][6][W]
+        const float *cf = P.ckf + P.S.off_ckf[s] + ((size_t)ch * (H4 + 2) + gs) * 18 * W + xw;
+        const double *ca = P.cka + P.S.off_cka[s] + ((size_t)ch * (H4 + 2) + gs) * 6 * W + xw;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) { sa[p][q] = ld_at<float>(cf + (size_t)(p * 6 + q) * W, l4); sb[p][q] = ld_at<float>(cf + (size_t)(p * 6 + 3 + q) * W, l4); }
+#pragma unroll
+        for (int q = 0; q < 6; q++) acc[q] = ld_at<double>(ca + (size_t)q * W, l8);
+    }
+    auto hbase = [&](int g) -> const float * { // plane 0 of group g for this wave: the candidate's if it wrote these columns, else B's
+        const int sl = uni((int)s_slot[wv][g]);
+        return sl >= 0 ? h_own + (size_t)sl * 9 * W4 : h_b + (size_t)g * 9 * W4;
+    };
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Tail ring slots are relative to gs: group gs+r keeps its xy half in slot r mod 2 and its zw half in slot r mod 3.
+    float2 *ring_xy = reinterpret_cast<float2 *>(s_raw) + t;                             // + (slot*3 + plane) * 256
+    float2 *ring_zw = reinterpret_cast<float2 *>(s_raw + 2 * 3 * 256 * sizeof(float2)) + t;
+    float4 bufA[3], bufB[3];
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+        float4 g1 = zero4, g2 = zero4, g3 = zero4;
+        bufA[p] = zero4; bufB[p] = zero4;
+        if (gs <= H4) {
+            if (gs < H4) bufA[p] = ld_at<float4>(hbase(gs) + (size_t)p * W4, l16);
+            if (gs - 1 >= 0) g1 = ld_at<float4>(hbase(gs - 1) + (size_t)p * W4, l16);
+            if (gs - 2 >= 0) g2 = ld_at<float4>(hbase(gs - 2) + (size_t)p * W4, l16);
+            if (gs - 3 >= 0) g3 = ld_at<float4>(hbase(gs - 3) + (size_t)p * W4, l16);
+        }
+        ring_xy[(1 * 3 + p) * 256] = make_float2(g1.x, g1.y); ring_zw[(2 * 3 + p) * 256] = make_float2(g1.z, g1.w); // r = -1
+        ring_xy[(0 * 3 + p) * 256] = make_float2(g2.x, g2.y); ring_zw[(1 * 3 + p) * 256] = make_float2(g2.z, g2.w); // r = -2
+        ring_zw[(0 * 3 + p) * 256] = make_float2(g3.z, g3.w);                                                       // r = -3
+    }
+    int r2 = 0, r3 = 0; // (g - gs) mod 2, mod 3: wave-uniform ring slots
+#define SNES_V2GROUP(CUR, NXT)                                                                                                \
+    {                                                                                                                         \
+        if (g + 1 < H4) { const float *hp = hbase(g + 1); NXT[0] = ld_at<float4>(hp, l16); NXT[1] = ld_at<float4>(hp + W4, l16); NXT[2] = ld_at<float4>(hp + 2 * W4, l16); } \
+        else { NXT[0] = zero4; NXT[1] = zero4; NXT[2] = zero4; }                                                              \
+        /* inputs of the maps of row group g-1, consumed after the recurrence steps below */                                  \
+        float4 c_m1 = zero4, c_sd1 = zero4, c_a1 = zero4, c_x = zero4;                                                        \
+        double2 c_ra = make_double2(1.0, 1.0), c_rb = c_ra;                                                                   \
+        if (g >= 1) {                                                                                                         \
+            const size_t go = (size_t)(g - 1) * W4;                                                                           \
+            c_m1 = ld_at<float4>(m1_b + go, l16); c_sd1 = ld_at<float4>(sd1_b + go, l16); c_a1 = ld_at<float4>(a1_b + go, l16); \
+            c_ra = ld_at<double2>(r1_b + go, l32); c_rb = ld_at<double2>(r1_b + go + 2, l32);                                 \
+            const int sl = uni((int)s_slot[wv][g - 1]);                                                                       \
+            c_x = ld_at<float4>(sl >= 0 ? x_own + (size_t)sl * 3 * W4 : x_b + (size_t)(g - 1) * 3 * W4, l16);                 \
+        }                                                                                                                     \
+        float outp[3][4];                                                                                                     \
+        _Pragma("unroll") for (int p = 0; p < 3; p++) {                                                                       \
+            float2 *pz = ring_zw + (r3 * 3 + p) * 256, *px = ring_xy + (r2 * 3 + p) * 256;                                    \
+            const float2 tz = *pz, tx = *px; /* group g-3 second half, g-2 first half */                                      \
+            *pz = make_float2(CUR[p].z, CUR[p].w);                                                                            \
+            *px = make_float2(CUR[p].x, CUR[p].y);                                                                            \
+            SNES_VSTEP(tz.x + CUR[p].x, sa[p], sb[p], outp[p][0])                                                             \
+            SNES_VSTEP(tz.y + CUR[p].y, sb[p], sa[p], outp[p][1])                                                             \
+            SNES_VSTEP(tx.x + CUR[p].z, sa[p], sb[p], outp[p][2])                                                             \
+            SNES_VSTEP(tx.y + CUR[p].w, sb[p], sa[p], outp[p][3])                                                             \
+        }                                                                                                                     \
+        if (g >= 1) {                                                                                                         \
+            const float m1v[4] = {c_m1.x, c_m1.y, c_m1.z, c_m1.w}, sd1v[4] = {c_sd1.x, c_sd1.y, c_sd1.z, c_sd1.w};              \
+            const float a1v[4] = {c_a1.x, c_a1.y, c_a1.z, c_a1.w}, i2v[4] = {c_x.x, c_x.y, c_x.z, c_x.w};                     \
+            const double r1v[4] = {c_ra.x, c_ra.y, c_rb.x, c_rb.y};                                                           \
+            _Pragma("unroll") for (int q = 0; q < 4; q++)                                                                     \
+                maps_accumulate(acc, m1v[q], sd1v[q], a1v[q], r1v[q], outp[0][q], outp[1][q], outp[2][q], i2v[q]);            \
+        }                                                                                                                     \
+        r2 ^= 1; r3 = r3 == 2 ? 0 : r3 + 1;                                                                                   \
+    }
+    for (int g = gs; g <= H4; g++) {
+        SNES_V2GROUP(bufA, bufB)
+        g++;
+        if (g > H4) break;
+        SNES_V2GROUP(bufB, bufA)
+    }
+#undef SNES_V2GROUP
+    __syncthreads(); // the tail ring is dead: its space becomes the reduction scratch
+#pragma unroll
+    for (int q = 0; q < 6; q++) red[t][q] = active ? acc[q] : 0.0;
+    __syncthreads();
+    const int xp = t & (W - 1); // column inside the pair
+    for (int stride = W >> 1; stride > 0; stride >>= 1) {
+        if (xp < stride) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) red[t][q] += red[t + stride][q];
+        }
+        __syncthreads();
+    }
+    if (xp == 0 && active) {
+        double *o = P.part + (((size_t)k * G.nscales + s) * 3 + ch) * 6;
+#pragma unroll
+        for (int q = 0; q < 6; q++) o[q] = red[t][q];
+    }
+}
+#undef SNES_HSTEP
+#undef SNES_VSTEP
+
+// entry points: the H pass takes the lists of the wide scales (grid.y = list), the V pass the wide scales (grid.y = scale)
+__device__ __forceinline__ void sparse_h2_dispatch(const SparseParams &P) {
+    const int list = (int)blockIdx.y, s = list / kColBuckets;
+    if (s >= P.G.nscales || P.G.sw[s] < 64 || (list % kColBuckets) >= (P.G.sw[s] >> 6)) return;
+    if (s == 0) sparse_h2_body<true>(P, list); else sparse_h2_body<false>(P, list);
+}
+__global__ __launch_bounds__(64) void k_sparse_h2(SparseParams P) { sparse_h2_dispatch(P); }
+__global__ __launch_bounds__(256, 4) void k_sparse_v2(SparseParams P) { if ((int)blockIdx.y < P.G.nscales && P.G.sw[blockIdx.y] >= 64) sparse_v2_body(P, (int)blockIdx.y); }
+
+} // namespace snes
