@@ -154,18 +154,19 @@ __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int 
 #pragma unroll
                     for (int p = 0; p < 3; p++) { so[p * 64 + 0] = outp[p][0]; so[p * 64 + 4] = outp[p][1]; so[p * 64 + 8] = outp[p][2]; so[p * 64 + 12] = outp[p][3]; }
                     if (S0) { so[3 * 64 + 0] = r2[ul].x; so[3 * 64 + 4] = r2[ul].y; so[3 * 64 + 8] = r2[ul].z; so[3 * 64 + 12] = r2[ul].w; }
-                    if ((g & 3) == 0) { // 16 columns complete: 256-byte runs, 16 bytes per lane
+                    if ((g & 3) == 0) { // 16 columns complete: one store instruction per item = its NP planes as 256-byte runs
                         __syncthreads();
                         const int x0 = (g - 4) << 2; // first column of the run
-                        const long long o_h = ((long long)(x0 >> 6) << 8) + ((x0 & 63) << 2), o_x = (long long)x0 << 2;
-#pragma unroll
-                        for (int m = 0; m < NP * 4; m++) {
-                            const int idx = m * 64 + lane;
-                            const int item = idx / (NP * 16), rem = idx - item * (NP * 16), p = rem >> 4, c = rem & 15;
-                            const long long hb = s_hbase[item];
-                            if (hb >= 0) {
-                                const float4 v = *reinterpret_cast<const float4 *>(s_out + item * ISTR + p * 64 + c * 4);
-                                float *dst = (S0 && p == 3) ? P.store + s_xbase[item] + o_x + c * 4 : P.store + hb + (long long)p * 4 * W + o_h + c * 4;
+                        const int p = lane >> 4, c = lane & 15;
+                        // float offset of this lane's 16 bytes behind the item's base: plane p of the H output (XT4 block of x0), or the XYB plane (R4)
+                        const uint32_t o_l = (S0 && p == 3) ? (uint32_t)(x0 << 2) + (uint32_t)(c << 2) : (uint32_t)p * 4u * (uint32_t)W + (uint32_t)((x0 >> 6) << 8) + (uint32_t)((x0 & 63) << 2) + (uint32_t)(c << 2);
+#pragma unroll 4
+                        for (int m = 0; m < 16; m++) {
+                            const long long hb = s_hbase[m]; // wave-uniform
+                            if (hb < 0) continue;
+                            if (lane < NP * 16) {
+                                const float4 v = *reinterpret_cast<const float4 *>(s_out + m * ISTR + lane * 4);
+                                float *dst = P.store + ((S0 && p == 3) ? s_xbase[m] : hb) + o_l;
                                 *reinterpret_cast<float4 *>(dst) = v;
                             }
                         }
