@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_CANDIDATE = 263408  # 262,144 source RGBA8 + 1,024 tile map + 240 palette
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0  # G wave64 instructions/s: 1,024 SIMD-32s, 2 cycles per binary32 wave instruction, 2.4 GHz
 
 
 def cpu_baseline(img, sub_count, sub_size, flags, tile_palettes, palette, budget_s=12.0):
@@ -135,7 +136,10 @@ def main():
     ap.add_argument("--groups", type=int, default=4, help="--config images: batches stepped side by side on their own streams")
     ap.add_argument("--per-image-launches", action="store_true",
                     help="--config images: one stream and one set of launches per image instead of one launch per stage for all images")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="N > 1: strong (default; --batch candidates per call in total, sharded over the GPUs — north_star's metric) or weak "
+                         "(--batch per GPU); the other mode is measured as an extra")
+    ap.add_argument("--no-extras", action="store_true", help="skip the 64-candidate and other-scaling-mode legs")
     ap.add_argument("--config", choices=["rgb", "perceptual", "dither", "images"], default="rgb")
     ap.add_argument("--chunk", type=int, default=0, help="candidates per launch group (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -202,15 +206,34 @@ def main():
     scorer = HipShardScorer(image, device)
 
     n_total = args.batch * world if args.scaling == "weak" else args.batch
-    slots = S.schedule(sub_count, sub_size, args.warmup + args.steps)
+    n_slots = args.warmup + args.steps
+    slots = S.schedule(sub_count, sub_size, n_slots)
     seed = 1
 
-    def run(lo, hi):
+    def run(lo, hi, n):
         for i in range(lo, hi):
-            method, p, idx, ch, _ = slots[i]
-            # the benchmark scores n_total random candidates on every slot (method 0); the channel sweeps of
+            method, p, idx, ch, _ = slots[i % len(slots)]
+            # the benchmark scores n random candidates on every slot (method 0); the channel sweeps of
             # lib.rs:286-328 are exercised by the tests
-            sharded_step(scorer, S.METHOD_RANDOM, p, idx, ch, seed, i, n_total)
+            sharded_step(scorer, S.METHOD_RANDOM, p, idx, ch, seed, i, n)
+
+    def timed(lo, hi, n):
+        """Barrier + synchronize on both sides, max over ranks (the contract's timed region); seconds."""
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(lo, hi, n)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
 
     # The remap on its own (SURVEY §8d config 2 reports it beside remap + SSIMULACRA2): every candidate's palette_map, no error()
     remap = None
@@ -237,25 +260,32 @@ def main():
                  "note": "source pixels (as the 512 KiB per-slot pack), tile map and palette are cache-resident across candidates: "
                          "the HBM traffic of this kernel is the 64 KiB palette_map it writes per candidate"}
         del d_maps
-    run(0, args.warmup)
+    run(0, args.warmup, n_total)
     torch.cuda.synchronize()
     image.timing_enable(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.warmup, args.warmup + args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed(args.warmup, args.warmup + args.steps, n_total)
     tim = image.timing_read()
     image.timing_enable(False)
     err, best, _ = image.last_step()
+
+    # Beside the headline (never part of `value`): the reference's own batch — 64 candidates per optimizer call (lib.rs:205),
+    # sharded over the ranks like the headline — and, on several GPUs, the other scaling mode.
+    extras = {}
+    if not args.no_extras:
+        k64 = max(40, min(400, args.steps * 4))
+        run(n_slots, n_slots + 5, 64)
+        dt64 = timed(n_slots + 5, n_slots + 5 + k64, 64)
+        extras["reference_batch"] = {"candidates_per_step": 64, "value": 64 * k64 / dt64, "unit": "candidates/s", "ms_per_call": dt64 / k64 * 1e3,
+                                     "steps": k64, "note": "the reference's 64 candidates per optimizer call (lib.rs:205) on one image: latency-bound "
+                                                           "(one call = ~20 dependent launches); throughput mode (--config images) batches such calls over images"}
+        if world > 1:
+            other = "weak" if args.scaling == "strong" else "strong"
+            n_other = args.batch * world if other == "weak" else args.batch
+            ko = max(10, args.steps // 2)
+            run(n_slots + 1000, n_slots + 1003, n_other)
+            dto = timed(n_slots + 1003, n_slots + 1003 + ko, n_other)
+            extras[other] = {"scaling": other, "candidates_per_step": n_other, "value": n_other * ko / dto, "unit": "candidates/s",
+                             "ms_per_step": dto / ko * 1e3, "steps": ko}
 
     if rank == 0:
         total = n_total * args.steps
@@ -263,24 +293,34 @@ def main():
         # dominant kernel of the launch group
         sparse = (args.config in ("rgb", "perceptual") and os.environ.get("SNES_SPARSE", "1") != "0"
                   and n_total // world >= int(os.environ.get("SNES_SPARSE_MIN", "64")))
-        vname, hname = ("k_sparse_v", "k_sparse_h") if sparse else ("k_vpass_fast<scale0>", "k_hpass_fast<scale0>")
+        vname, hname = ("k_sparse_v2", "k_sparse_h2+k_sparse_h") if sparse else ("k_vpass_fast<scale0>", "k_hpass_fast<scale0>")
         dom = vname if tim["vpass0_ms"] >= tim["hpass0_ms"] else hname
         dom_ms = max(tim["vpass0_ms"], tim["hpass0_ms"]) / max(1, tim["launches"])
         per_launch = tim["candidates"] / max(1, tim["launches"])
         achieved = ALGO_BYTES_PER_CANDIDATE * per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        # HBM bytes of the dominant kernel per launch, from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as the
-        # gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE), scaled to this run's candidates per launch; counters
-        # cannot be collected from inside the benchmark, so this is null for kernels without a committed measurement
-        traffic, traffic_src = None, None
+        # Counters cannot be collected from inside the benchmark: HBM bytes and VALU instructions of the dominant kernel come
+        # from the committed rocprofv3 PMC passes of this configuration (profiles/r2_pmc_<config>.json, one pass per counter
+        # set; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE), scaled from that run's
+        # candidates per launch to this run's.  null where no measurement of the kernel is committed.
+        traffic, traffic_src, valu = None, None, None
         try:
-            pmc_file = os.path.join(ROOT, "profiles", "r1_e_pmc_hbm_rgb_batch1024.json")
-            if sparse and args.config == "rgb":
-                pmc = json.load(open(pmc_file))["counters"]
-                key = "snes::" + dom
-                traffic = (2.0 * pmc["FETCH_SIZE"][key]["max_KB"] + pmc["WRITE_SIZE"][key]["max_KB"]) * 1024.0 * per_launch / 1024.0
-                traffic_src = "profiles/r1_e_pmc_hbm_rgb_batch1024.json (measured per 1,024-candidate launch, scaled)"
-        except (OSError, KeyError, ValueError):
-            traffic = None
+            pmc_path = os.path.join("profiles", "r2_pmc_%s.json" % args.config)
+            pmc = json.load(open(os.path.join(ROOT, pmc_path)))
+            k = pmc["kernels"].get("snes::" + dom.split("+")[0].split("<")[0]) or pmc["kernels"].get("void snes::" + dom.split("<")[0] + "<true>")
+            scale = per_launch / float(pmc["candidates_per_launch"])
+            if k and "hbm_bytes_corrected_per_dispatch" in k:
+                traffic = k["hbm_bytes_corrected_per_dispatch"] * scale
+                traffic_src = "%s (measured at %d candidates per launch, scaled)" % (pmc_path, pmc["candidates_per_launch"])
+            if k and "SQ_INSTS_VALU" in k:
+                # the bound that does bind: issued VALU wave-instructions against the chip's issue rate (256 CUs x 4 SIMDs, one
+                # wave64 instruction per 2 cycles at 2.4 GHz for binary32, half that for binary64: an upper bound on the peak)
+                per_cand = k["SQ_INSTS_VALU"]["mean"] / float(pmc["candidates_per_launch"])
+                rate = per_cand * per_launch / (dom_ms * 1e-3)
+                valu = {"kernel": dom, "wave_instructions_per_candidate": per_cand, "achieved_Ginstr_s": rate / 1e9,
+                        "peak_Ginstr_s": VALU_PEAK_GINSTR, "frac": rate / 1e9 / VALU_PEAK_GINSTR,
+                        "VALUBusy_percent": k.get("VALUBusy", {}).get("mean"), "source": pmc_path}
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
+            pass
         out = {
             "metric": "candidate palettes scored/sec", "value": value, "unit": "candidates/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -298,6 +338,8 @@ def main():
                          "pipeline_achieved": value / world * ALGO_BYTES_PER_CANDIDATE / 1e9,
                          "pipeline_frac": value / world * ALGO_BYTES_PER_CANDIDATE / 1e9 / HBM_PEAK_GBS},
         }
+        out["valu_roofline"] = valu
+        out.update(extras)
         out["remap_only"] = remap
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(img, sub_count, sub_size, flags, tile_palettes, palette)

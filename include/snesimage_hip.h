@@ -164,9 +164,10 @@ void snesimage_debug_fail_alloc(int32_t n);
 /* Launch timing by the library's own HIP events on the stream each launch group runs on (bench.py's roofline leg).
  * While enabled, every scoring launch group records events; timing_read() returns summed milliseconds:
  *   ms3[0] = the whole launch group (all kernels that score one chunk of candidates);
- *   ms3[1] = the H pass: k_sparse_h (one launch, every scale) on the group-sparse path, k_hpass* at scale 0 otherwise;
- *   ms3[2] = the V pass, the dominant kernel: k_sparse_v alone (one launch, every scale; the wait for B's checkpoints
- *            and k_sparse_order come before the opening event) on the group-sparse path, k_vpass* at scale 0 otherwise;
+ *   ms3[1] = the H pass: k_sparse_h2 + k_sparse_h (wide and narrow scales) on the group-sparse path, k_hpass* at scale 0 otherwise;
+ *   ms3[2] = the V pass, the dominant kernel: k_sparse_v2 alone (one launch, the scales at least 64 wide; the wait for
+ *            B's checkpoints and k_sparse_order come before the opening event) on the group-sparse path, k_vpass* at
+ *            scale 0 otherwise;
  * plus the number of launch groups and the candidates they scored since timing was enabled. */
 int32_t snesimage_timing_enable(snesimage_ctx *ctx, int32_t on);
 int32_t snesimage_timing_read(snesimage_ctx *ctx, double *ms3, uint64_t *launches,

@@ -523,10 +523,10 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     if (sp.side || stream != c->stream) HIPCHK(hipStreamWaitEvent(stream, sp.side ? sp.ev_base_done : c->ev_ready, 0)); // checkpoints and H output of B
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[2], stream));
     if (c->sp.lpt) { hipLaunchKernelGGL(k_sparse_order, dim3(1), dim3(1024), 0, stream, P, sp.order + P.k0); P.order = sp.order + P.k0; }
-    if (c->timing) HIPCHK(hipEventRecord(tr.ev[3], stream)); // ev[3]..ev[4] bracket k_sparse_v alone (every scale, one launch)
+    if (c->timing) HIPCHK(hipEventRecord(tr.ev[3], stream));
     hipLaunchKernelGGL(k_sparse_v2, dim3(nc * 3, (unsigned)P.s_first), dim3(256), 0, stream, P);
+    if (c->timing) HIPCHK(hipEventRecord(tr.ev[4], stream)); // ev[3]..ev[4]: k_sparse_v2 alone
     if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_v, dim3((nc * 3 + 7) / 8, (unsigned)G.nscales), dim3(256), 0, stream, P); // narrow scales: >= 8 pairs per block
-    if (c->timing) HIPCHK(hipEventRecord(tr.ev[4], stream));
     hipLaunchKernelGGL(k_final_score, dim3((nc + 63) / 64), dim3(64), 0, stream, sp.part + (size_t)P.k0 * G.nscales * 18, (int)nc, G, d_errors, err_stride, err_offset, P.item_count, (int)kItemLists);
     HIPCHK(hipGetLastError());
     if (c->timing) { HIPCHK(hipEventRecord(tr.ev[5], stream)); c->t_pending.push_back(tr); }
