@@ -75,7 +75,10 @@ def bench_images(args, torch, dist, S, world, rank, local_rank, device, force_di
     mine = shard_images(args.images * world, rank, world)
     batch = ImageBatch.synthetic(mine, sub_count, sub_size, device=local_rank, candidates=args.batch, host_threads=args.host_threads,
                                  batched=not args.per_image_launches, groups=args.groups, perceptual=args.perceptual)
-    batch.initialize(drop_failed=True)  # untimed: TileAssignment + Clustering of every image
+    t_init = time.perf_counter()
+    batch.initialize(drop_failed=True)  # untimed: TileAssignment + Clustering of every image (the k-means initialisers)
+    torch.cuda.synchronize()
+    t_init = time.perf_counter() - t_init
     if batch.dropped and not args.perceptual:
         # the synthetic RGB images never violate cogset's precondition; a drop here would silently shrink the workload
         raise SystemExit("bench.py --config images: %d image(s) failed k-means initialisation (%s); the measurement is void"
@@ -107,7 +110,7 @@ def bench_images(args, torch, dist, S, world, rank, local_rank, device, force_di
                                    "%s, no dither, %d candidates per optimizer call per image, one call on every "
                                    "image per step, remap + SSIMULACRA2 per candidate, no collective" % (
                                        len(mine), "CIEDE2000 (--perceptual-palettes)" if args.perceptual else "RGB redmean distance", args.batch),
-                       "images_per_gpu": len(batch), "dropped_at_init": batch.dropped, "batch": args.batch, "config": "images", "host_threads": args.host_threads,
+                       "images_per_gpu": len(batch), "dropped_at_init": batch.dropped, "init_seconds": t_init, "batch": args.batch, "config": "images", "host_threads": args.host_threads,
                        "launches": "per image" if args.per_image_launches else "one per stage for all images",
                        "mean_final_error": sum(errs) / len(errs)},
             "roofline": {"bound": "hbm", "kernel": "pipeline (kernels of different images overlap; no per-kernel timing in this mode)",
