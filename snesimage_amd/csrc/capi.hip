@@ -146,6 +146,10 @@ struct snesimage_ctx {
         CandMeta *meta = nullptr; unsigned int *items = nullptr; int *item_count = nullptr; long long item_stride = 0; int *order = nullptr, *first = nullptr;
         uint4 *plist = nullptr; int *plist_count = nullptr; bool plist_valid = false;
         hipStream_t base_stream = nullptr; hipEvent_t ev_base_in = nullptr, ev_base_done = nullptr; // B's H and V passes run beside the candidates' scan/down/H
+        // --dither (RGB distance): B dithered once per slot (k_dither MODE 1) and the candidates resumed from its checkpoints (MODE 2)
+        uint8_t *dmaps = nullptr, *dmapsC4 = nullptr; // [lane][cap][W*H] candidates' palette_maps, row-major and C4
+        uint8_t *bmap = nullptr, *bmapC4 = nullptr, *bcand = nullptr; unsigned long long *dpack = nullptr; double *ckd = nullptr; uint32_t slot_ci = 0;
+        int base_sp = -1, base_si = -1; // slot B was built for (with --dither the pack does not depend on the slot, B does)
     } sp;
     // step state
     uint8_t *d_cand = nullptr; uint32_t cand_cap = 0;
@@ -454,6 +458,14 @@ int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
     sp.plist_count = sp.item_count + (size_t)kItemLists * (c->nlanes + 1);
     sp.counters_cleared = true;
     HIPCHK(dmalloc(&sp.plist, sizeof(uint4) * c->npx));
+    if (c->dither) {
+        dfree(sp.dmaps); dfree(sp.dmapsC4); dfree(sp.bmap); dfree(sp.bmapC4); dfree(sp.bcand); dfree(sp.dpack); dfree(sp.ckd);
+        HIPCHK(dmalloc(&sp.dmaps, c->npx * (size_t)need * c->nlanes));
+        HIPCHK(dmalloc(&sp.dmapsC4, c->npx * (size_t)need * c->nlanes));
+        HIPCHK(dmalloc(&sp.bmap, c->npx)); HIPCHK(dmalloc(&sp.bmapC4, c->npx)); HIPCHK(dmalloc(&sp.bcand, 64));
+        HIPCHK(dmalloc(&sp.dpack, sizeof(unsigned long long) * c->npx));
+        HIPCHK(dmalloc(&sp.ckd, sizeof(double) * 3 * c->W * (c->H / 4 + 1)));
+    }
     sp.cap = need; sp.plist_valid = false;
     return SNES_OK;
 }
@@ -470,17 +482,39 @@ SparseParams sparse_params(snesimage_ctx *c, uint32_t lane) {
     P.items = sp.items + (size_t)lane * sp.item_stride * kItemLists; P.item_count = sp.item_count + (size_t)lane * kItemLists; P.item_stride = sp.item_stride; // lane == nlanes: B
     P.ckf = sp.ckf; P.cka = sp.cka; P.part = sp.part; P.first = sp.first; P.ckh = sp.ckh;
     for (P.s_first = 0; P.s_first < c->G.nscales && c->G.sw[P.s_first] >= 64; P.s_first++) {} // first narrow scale
+    if (c->dither) {
+        const uint32_t l = lane < c->nlanes ? lane : 0;
+        P.use_maps = 1; P.sub_size = (int)c->sub_size; P.slot_ci = sp.slot_ci; P.subC4 = c->d_subC4; P.tile_pal = c->d_tile_pal;
+        P.maps = sp.dmaps + (size_t)l * sp.cap * c->npx; P.mapsC4 = sp.dmapsC4 + (size_t)l * sp.cap * c->npx; P.bmap = sp.bmap; P.bmapC4 = sp.bmapC4;
+    }
     return P;
 }
 
 // B of the current slot: compact list of contested pixels, then the pipeline once with checkpoints (main stream)
-int32_t sparse_base_pass(snesimage_ctx *c) {
+int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si) {
     auto &sp = c->sp;
     const Geom &G = c->G;
     if (!sp.plist_valid) {
         if (!sp.counters_cleared) HIPCHK(hipMemsetAsync(sp.item_count + (size_t)c->nlanes * kItemLists, 0, sizeof(int) * (kItemLists + 1), c->stream)); // normally k_prep did it
         sp.counters_cleared = false; // about to be used
-        hipLaunchKernelGGL(k_build_plist, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, c->d_pack, (int)c->npx, sp.plist, sp.plist_count);
+        const unsigned long long *win_pack = c->d_pack;
+        if (c->dither) {
+            // B = the image dithered with the slot's entry out of play: the slot takes the colour of another entry j0 of its
+            // subpalette (k_dither MODE 1), which records, per pixel, the dithered target and the key a candidate has to beat
+            const uint32_t j0 = c->sub_size > 1 ? ((uint32_t)si + 1u) % c->sub_size : (uint32_t)si;
+            sp.slot_ci = (uint32_t)(sp_idx * (int)c->sub_size + si);
+            HIPCHK(hipMemcpyAsync(sp.bcand, c->d_colors + 3 * (size_t)(sp_idx * (int)c->sub_size + (int)j0), 3, hipMemcpyDeviceToDevice, c->stream));
+            float *btab = sp.cand_tab + 8 * (size_t)(c->nlanes * sp.cap);
+            hipLaunchKernelGGL(k_candidate_tables, dim3(1), dim3(64), 0, c->stream, sp.bcand, 1, c->d_eotf, btab);
+            DitherParams Dp{};
+            Dp.orig = c->d_orig; Dp.tile_pal = c->d_tile_pal; Dp.pal_rgb8 = c->d_pal_rgb8; Dp.cand_tab = btab; Dp.maps = sp.bmap; Dp.mapsC4 = sp.bmapC4;
+            Dp.W = (int)c->W; Dp.H = (int)c->H; Dp.sub_size = (int)c->sub_size; Dp.ncol = c->ncol; Dp.slot_ci = sp.slot_ci;
+            Dp.rec_pack = sp.dpack; Dp.ck_out = sp.ckd; Dp.excl_sub = sp_idx; Dp.excl_si = si; Dp.excl_j0 = (int)j0;
+            if (c->sub_size == 15) hipLaunchKernelGGL((k_dither<false, 15, 1>), dim3(1), dim3(128), 0, c->stream, Dp);
+            else hipLaunchKernelGGL((k_dither<false, 0, 1>), dim3(1), dim3(128), 0, c->stream, Dp);
+            win_pack = sp.dpack;
+        }
+        hipLaunchKernelGGL(k_build_plist, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, win_pack, (int)c->npx, sp.plist, sp.plist_count);
         SparseParams P = sparse_params(c, c->nlanes); // B has its own item list and counters
         P.is_base = 1; P.ncand = 1; P.k0 = P.base;
         hipLaunchKernelGGL(k_sparse_scan, dim3(1), dim3(1024), 0, c->stream, P);
@@ -510,7 +544,16 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     snesimage_ctx::TimingRec tr{}; tr.n = nc;
     if (c->timing) { for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&tr.ev[i])); HIPCHK(hipEventRecord(tr.ev[0], stream)); }
     hipLaunchKernelGGL(k_candidate_tables, dim3((nc + 63) / 64), dim3(64), 0, stream, d_rgb5, (int)nc, c->d_eotf, sp.cand_tab + 8 * (size_t)P.k0);
-    if (c->perceptual) {
+    if (c->dither) { // first pixel each candidate takes from B, then its own Floyd-Steinberg run from that 4-row group on
+        hipLaunchKernelGGL(k_dither_first, dim3((nc + 15) / 16), dim3(1024), 0, stream, P);
+        DitherParams Dp{};
+        Dp.orig = c->d_orig; Dp.tile_pal = c->d_tile_pal; Dp.pal_rgb8 = c->d_pal_rgb8; Dp.cand_tab = sp.cand_tab + 8 * (size_t)P.k0;
+        Dp.maps = const_cast<uint8_t *>(P.maps); Dp.mapsC4 = const_cast<uint8_t *>(P.mapsC4);
+        Dp.W = (int)c->W; Dp.H = (int)c->H; Dp.sub_size = (int)c->sub_size; Dp.ncol = c->ncol; Dp.slot_ci = sp.slot_ci;
+        Dp.first_group = sp.first; Dp.first_k0 = P.k0; Dp.ck_in = sp.ckd; Dp.bmap = sp.bmap; Dp.bmapC4 = sp.bmapC4;
+        if (c->sub_size == 15) hipLaunchKernelGGL((k_dither<false, 15, 2>), dim3(nc), dim3(128), 0, stream, Dp);
+        else hipLaunchKernelGGL((k_dither<false, 0, 2>), dim3(nc), dim3(128), 0, stream, Dp);
+    } else if (c->perceptual) {
         hipLaunchKernelGGL(k_candidate_lab, dim3((nc + 63) / 64), dim3(64), 0, stream, sp.cand_tab + 8 * (size_t)P.k0, (int)nc, c->d_lab_eotf, sp.cand_lab + 3 * (size_t)P.k0);
         HIPCHK(hipMemsetAsync(sp.bitmap + (size_t)P.k0 * (c->npx / 32), 0, sizeof(uint32_t) * (c->npx / 32) * nc, stream));
         hipLaunchKernelGGL(k_sparse_scan_lab, dim3((nc + 3) / 4), dim3(256), 0, stream, P);
@@ -528,6 +571,10 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[4], stream)); // ev[3]..ev[4]: k_sparse_v2 alone
     if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_v, dim3((nc * 3 + 7) / 8, (unsigned)G.nscales), dim3(256), 0, stream, P); // narrow scales: >= 8 pairs per block
     hipLaunchKernelGGL(k_final_score, dim3((nc + 63) / 64), dim3(64), 0, stream, sp.part + (size_t)P.k0 * G.nscales * 18, (int)nc, G, d_errors, err_stride, err_offset, P.item_count, (int)kItemLists);
+    if (c->dither) { // the lane remembers the map of its best candidate so far: the commit adopts the winner's instead of dithering again
+        uint8_t *bm = lane == 0 ? c->d_bestmap : c->extra[lane - 1].d_bestmap; BestRec *br = lane == 0 ? c->d_bestrec : c->extra[lane - 1].d_bestrec;
+        hipLaunchKernelGGL(k_keep_best, dim3(1), dim3(1024), 0, stream, d_errors, err_stride, err_offset, (int)nc, P.maps, (int)c->npx, br, bm);
+    }
     HIPCHK(hipGetLastError());
     if (c->timing) { HIPCHK(hipEventRecord(tr.ev[5], stream)); c->t_pending.push_back(tr); }
     return SNES_OK;
@@ -549,13 +596,18 @@ int32_t score_list(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t n, double *
     uint32_t chunk = (n + c->nlanes - 1) / c->nlanes;
     if (chunk < 64) chunk = 64;
     if (chunk > c->chunk) chunk = c->chunk;
-    const bool sparse = c->sp.enabled && !d_maps_out && sp >= 0 && n >= c->sp.min_n && c->pack_mode == 2;
+    const bool sparse = c->sp.enabled && !d_maps_out && sp >= 0 && n >= c->sp.min_n && c->pack_mode == (c->dither ? 1 : 2);
     CHECK(alloc_workspace(c, sparse ? 1 : chunk));
     CHECK(ensure_tables(c));
     CHECK(ensure_source(c));
     const uint32_t nchunks = (n + chunk - 1) / chunk;
     const uint32_t nl = nchunks < c->nlanes ? nchunks : c->nlanes;
-    if (sparse) { CHECK(sparse_alloc(c, chunk)); CHECK(sparse_base_pass(c)); }
+    if (sparse) {
+        CHECK(sparse_alloc(c, chunk));
+        if (c->dither && (c->sp.base_sp != sp || c->sp.base_si != si)) c->sp.plist_valid = false;
+        CHECK(sparse_base_pass(c, sp, si));
+        c->sp.base_sp = sp; c->sp.base_si = si;
+    }
     if (c->dither) { hipLaunchKernelGGL(k_reset_best, dim3(1), dim3(64), 0, c->stream, c->d_bestrecs_all, (int)c->nlanes); c->best_valid = true; }
     if (nl > 1) {
         HIPCHK(hipEventRecord(c->ev_ready, c->stream)); // pack, tables, candidates are ready
@@ -730,7 +782,8 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     c->K = make_blur_constants();
     if (const char *e = getenv("SNES_CHUNK")) { int v = atoi(e); if (v > 0) c->chunk = (uint32_t)v; }
     if (const char *e = getenv("SNES_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->nlanes = (uint32_t)v; }
-    c->sp.enabled = (h == 256) && !c->dither; // the group-sparse path covers the no-dither remap (RGB keys or CIEDE2000) at the full size
+    // the group-sparse path covers, at the full size, the no-dither remap (RGB keys or CIEDE2000) and the RGB Floyd-Steinberg remap
+    c->sp.enabled = (h == 256) && !(c->dither && c->perceptual);
     if (const char *e = getenv("SNES_SPARSE")) c->sp.enabled = c->sp.enabled && atoi(e) != 0;
     if (const char *e = getenv("SNES_BASE_STREAM")) c->sp.side = atoi(e) != 0;
     if (const char *e = getenv("SNES_LPT")) c->sp.lpt = atoi(e) != 0;
@@ -830,7 +883,8 @@ void snesimage_destroy(snesimage_ctx *c) {
     dfree(c->d_cand); dfree(c->d_cand_sel); dfree(c->d_errs); dfree(c->d_errs_sel); dfree(c->d_inc_err); dfree(c->d_last); dfree(c->d_scratch_err); dfree(c->d_dummy_cand);
     for (auto &L : c->extra) { if (L.stream) (void)hipStreamSynchronize(L.stream); dfree(L.d_mapsC4); dfree(L.d_mapsR4); dfree(L.d_work); dfree(L.d_cand_tab); dfree(L.d_cand_lab); dfree(L.d_part); dfree(L.d_maps); dfree(L.d_mapsT); if (L.done) (void)hipEventDestroy(L.done); if (L.stream) (void)hipStreamDestroy(L.stream); }
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
-    { auto &q = c->sp; if (q.base_stream) { (void)hipStreamSynchronize(q.base_stream); (void)hipStreamDestroy(q.base_stream); (void)hipEventDestroy(q.ev_base_in); (void)hipEventDestroy(q.ev_base_done); } dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.order); dfree(q.first); dfree(q.cand_lab); dfree(q.bitmap); dfree(q.ckh); }
+    { auto &q = c->sp; if (q.base_stream) { (void)hipStreamSynchronize(q.base_stream); (void)hipStreamDestroy(q.base_stream); (void)hipEventDestroy(q.ev_base_in); (void)hipEventDestroy(q.ev_base_done); } dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.order); dfree(q.first); dfree(q.cand_lab); dfree(q.bitmap); dfree(q.ckh);
+      dfree(q.dmaps); dfree(q.dmapsC4); dfree(q.bmap); dfree(q.bmapC4); dfree(q.bcand); dfree(q.dpack); dfree(q.ckd); }
     kmeans_free(c->km);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;

@@ -51,6 +51,15 @@ struct DitherParams {
     uint8_t *maps, *mapsC4; // row-major and the column-blocked layout of kernels_fast.hpp (k_maps_relayout derives the others)
     int W, H, sub_size, ncol; uint32_t slot_ci; int perceptual;
     const int *skip; // optional device flag: nonzero = the map is already in place, leave at once
+    // MODE 1 (the base image B of a slot, dithered once with the slot's entry out of play) additionally leaves behind:
+    unsigned long long *rec_pack; // per pixel, in the pack's format: lo = dithered target (8-bit, clamped and rounded as lib.rs:773-778) | B's colour index << 24,
+                                  // hi = the key a candidate must beat to take the pixel (0 outside the slot's subpalette): the win test of k_dither_first
+    double *ck_out;               // [H/4 + 1][W][3]: diffused-error state entering row 4g (the v values of row 4g-1), g >= 1
+    int excl_sub, excl_si, excl_j0; // slot (subpalette, index); j0 = the other entry whose colour stands in for the slot's (see k_dither)
+    // MODE 2 (a candidate resumed where it first differs from B):
+    const int *first_group;       // per candidate: 4-row group holding its first won pixel in raster order (H/4 if it wins nothing); P.k0 offsets the index
+    int first_k0;
+    const double *ck_in; const uint8_t *bmap, *bmapC4; // B's checkpoints and map (rows above the first group are B's)
 };
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -78,9 +87,19 @@ __device__ __forceinline__ uint32_t dither_group_min(const uint4 *__restrict__ e
 }
 
 // PERC: CIEDE2000 in Lab (the --perceptual-palettes remap); SUB: subpalette size known at compile time (0 = read it from P)
-template <bool PERC, int SUB>
+// MODE 0: the whole image.
+// MODE 1: the same for the base image B of a slot — the candidate colour handed in is the colour of another entry j0 of the
+//         slot's subpalette, so the slot's entry duplicates j0: the nearest-entry search then returns the best OTHER entry
+//         (a duplicate never changes the minimum key; where the duplicate itself is returned, the lowest-index minimum
+//         among the others is j0), its key is what a candidate has to beat, and the diffused error is that of the image
+//         without the slot's entry.  Records the win-test word per pixel and the row state at every 4-row boundary.
+// MODE 2: a candidate, resumed: Floyd-Steinberg is causal in raster order, so up to its first won pixel the candidate's
+//         run IS B's run.  Rows above the 4-row group of that pixel are copied from B's map, the state entering the group
+//         comes from B's checkpoint, and only the rows from there on are dithered (all of them: the error spreads).
+template <bool PERC, int SUB, int MODE = 0>
 __global__ __launch_bounds__(128) void k_dither(DitherParams P) {
     __shared__ uint4 s_ent[256];
+    __shared__ double s_ck[MODE == 2 ? 256 * 3 : 1]; // MODE 2: B's state entering the first row
     __shared__ float s_lab[PERC ? 256 * 3 : 1];
     __shared__ float s_eotf[PERC ? 256 : 1];
     __shared__ double ring[128][4][3];
@@ -106,25 +125,40 @@ __global__ __launch_bounds__(128) void k_dither(DitherParams P) {
     for (int q = 0; q < 4; q++) { ring[j][q][0] = 0.0; ring[j][q][1] = 0.0; ring[j][q][2] = 0.0; }
     __syncthreads();
     const double w0 = 7.0 / 16.0, w1 = 3.0 / 16.0, w2 = 5.0 / 16.0, w3 = 1.0 / 16.0, mult = 0.8;
-    const int rows_per_thread = (H + 127) / 128; // 1 or 2 (H <= 256)
-    const int total_steps = 2 * 127 + rows_per_thread * W;
-    double left[3] = {0.0, 0.0, 0.0}; // v(x-1, y) of this thread's current row
     uint8_t *map = P.maps + (size_t)cand * W * H;
     uint32_t *map4 = reinterpret_cast<uint32_t *>(map);
     uint32_t *mapC4 = P.mapsC4 ? reinterpret_cast<uint32_t *>(P.mapsC4 + (size_t)cand * W * H) : nullptr;
+    int y0 = 0; // first row to dither
+    if (MODE == 2) {
+        const int g0 = P.first_group[P.first_k0 + cand];
+        y0 = min(4 * g0, H);
+        // rows above are B's
+        const uint32_t *b4 = reinterpret_cast<const uint32_t *>(P.bmap), *bC4 = reinterpret_cast<const uint32_t *>(P.bmapC4);
+        for (int i = j; i < y0 * (W >> 2); i += 128) map4[i] = b4[i];
+        if (mapC4) for (int i = j; i < y0 * (W >> 2); i += 128) { const int q = i / y0, yy = i - q * y0; mapC4[q * H + yy] = bC4[q * H + yy]; }
+        if (y0 >= H) return;
+        if (y0 > 0) for (int i = j; i < W * 3; i += 128) s_ck[i] = P.ck_in[(size_t)g0 * W * 3 + i];
+        __syncthreads();
+    }
+    const int nrows = H - y0;
+    const int rows_per_thread = (nrows + 127) / 128; // 1 or 2 (H <= 256)
+    const int nth = nrows < 128 ? nrows : 128;
+    const int total_steps = 2 * (nth - 1) + rows_per_thread * W;
+    double left[3] = {0.0, 0.0, 0.0}; // v(x-1, y) of this thread's current row
     uint32_t macc = 0; // the four map bytes of the current x quad: one word store instead of scattered byte stores
     const int up = (j + 127) & 127; // thread owning row y-1
     // the source pixels of the NEXT x quad are fetched while the current quad is processed (the step is a dependent chain)
     const uint4 *orig4 = reinterpret_cast<const uint4 *>(P.orig);
-    uint4 o_cur = make_uint4(0, 0, 0, 0), o_nxt = (j < H) ? orig4[(size_t)j * (W >> 2)] : make_uint4(0, 0, 0, 0);
+    uint4 o_cur = make_uint4(0, 0, 0, 0), o_nxt = (y0 + j < H) ? orig4[(size_t)(y0 + j) * (W >> 2)] : make_uint4(0, 0, 0, 0);
     for (int t = 0; t < total_steps; t++) {
         const int local = t - 2 * j; // position in this thread's 512-pixel stream
-        const int x = local & (W - 1), y = j + 128 * (local >> 8);
+        const int x = local & (W - 1), y = y0 + j + 128 * (local >> 8);
         const bool act = local >= 0 && local < rows_per_thread * W && y < H;
         if (act) {
             // every operand is fetched unconditionally and the border cases are selects, so the step has no divergent
             // branches and its LDS reads are all in flight together
             const double *ru0 = ring[up][(x - 1) & 3], *ru1 = ring[up][x & 3], *ru2 = ring[up][(x + 1) & 3];
+            if (MODE == 2 && y == y0) { ru0 = s_ck + 3 * ((x - 1) & (W - 1)); ru1 = s_ck + 3 * x; ru2 = s_ck + 3 * ((x + 1) & (W - 1)); } // the row above is B's
             const int base = (int)s_tile[(x >> 3) + (y >> 3) * (W >> 3)] * sub_size;
             double r0[3], r1[3], r2[3];
 #pragma unroll
@@ -132,7 +166,7 @@ __global__ __launch_bounds__(128) void k_dither(DitherParams P) {
             if ((x & 3) == 0) { // this thread's stream continues with (x+4, y), then row y+128
                 o_cur = o_nxt;
                 const int ln = local + 4;
-                const int xn = ln & (W - 1), yn = j + 128 * (ln >> 8);
+                const int xn = ln & (W - 1), yn = y0 + j + 128 * (ln >> 8);
                 if (ln < rows_per_thread * W && yn < H) o_nxt = orig4[((size_t)yn * W + xn) >> 2];
             }
             const uint32_t o = (x & 2) ? ((x & 1) ? o_cur.w : o_cur.z) : ((x & 1) ? o_cur.y : o_cur.x);
@@ -154,6 +188,7 @@ __global__ __launch_bounds__(128) void k_dither(DitherParams P) {
                 tq[c] = (uint32_t)(tr + ((cl - tr >= 0.5) ? 1.0 : 0.0));
             }
             int best = 0;
+            uint32_t key_min = 0; // MODE 1: key of the nearest entry
             if (!PERC) {
                 const uint32_t t1 = tq[0] | (tq[2] << 16), tw = (8u * tq[0]) | ((0u - 8u * tq[0]) << 16);
                 const int tg = (int)tq[1];
@@ -166,6 +201,7 @@ __global__ __launch_bounds__(128) void k_dither(DitherParams P) {
                         if (i0 == 0 || (g >> 3) < (bk >> 3)) { bk = g; bbase = i0; }
                     }
                     best = bbase + (int)(bk & 7);
+                    key_min = bk >> 3;
                 } else {
                     int i0 = 0;
                     for (; i0 + 8 <= sub_size; i0 += 8) {
@@ -178,6 +214,7 @@ __global__ __launch_bounds__(128) void k_dither(DitherParams P) {
                         const uint32_t g = dither_group_min<1>(s_ent + base + i0, t1, tw, tg) >> 3;
                         if (i0 == 0 || g < bkey) { bkey = g; best = i0; }
                     }
+                    key_min = bkey;
                 }
             } else {
                 Lab tl = linear_to_lab(s_eotf[tq[0]], s_eotf[tq[1]], s_eotf[tq[2]]);
@@ -187,6 +224,13 @@ __global__ __launch_bounds__(128) void k_dither(DitherParams P) {
                     float d = ciede2000(el, tl);
                     if (i == 0 || d < bd) { bd = d; best = i; }
                 }
+            }
+            if (MODE == 1) { // B: the slot's entry is a stand-in for j0 (same colour, hence same key and same diffused error)
+                const bool in_sub = base == P.excl_sub * sub_size;
+                if (in_sub && best == P.excl_si) best = P.excl_j0;
+                const uint32_t thr = (in_sub && opaque) ? (sub_size == 1 ? 0xffffffffu : key_min + (P.excl_si < best ? 1u : 0u)) : 0u;
+                const uint32_t ci = opaque ? (uint32_t)(base + best) : (uint32_t)P.ncol + 1u;
+                P.rec_pack[(size_t)y * W + x] = (unsigned long long)(tq[0] | (tq[1] << 8) | (tq[2] << 16) | (ci << 24)) | ((unsigned long long)thr << 32);
             }
             const uint8_t m = opaque ? (uint8_t)best : 0;
             macc = (macc >> 8) | ((uint32_t)m << 24);
@@ -206,6 +250,7 @@ __global__ __launch_bounds__(128) void k_dither(DitherParams P) {
             // Row y-1 is two columns ahead (t = x + 2y): at this step it writes slot (x+2)&3 while this thread read slots
             // (x-1), x, (x+1) & 3 — never the same slot, so one barrier per step orders everything.
             ring[j][x & 3][0] = v[0]; ring[j][x & 3][1] = v[1]; ring[j][x & 3][2] = v[2];
+            if (MODE == 1 && (y & 3) == 3 && y + 1 < H) { double *co = P.ck_out + ((size_t)((y + 1) >> 2) * W + x) * 3; co[0] = v[0]; co[1] = v[1]; co[2] = v[2]; }
         }
         __syncthreads();
     }

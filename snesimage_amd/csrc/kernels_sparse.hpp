@@ -65,6 +65,8 @@ struct SparseParams {
     float *store; CandMeta *meta;
     unsigned int *items; int *item_count; long long item_stride; // per (scale, first column block b): items[(s*4+b)*item_stride + i] = cand*256 + slot*4 + ch
     float *ckf; double *cka; double *part; float *ckh;
+    // --dither: a candidate's pixels come from its own palette_map (k_dither, MODE 2) instead of the pack's win test; B's from bmap
+    int use_maps, sub_size; uint32_t slot_ci; const uint8_t *maps, *mapsC4, *bmap, *bmapC4, *subC4, *tile_pal; // maps: + (k - k0) * W * H
     int s_first; // the general H and V bodies skip scales below this one (the wide scales run the bodies of kernels_sparse2.hpp)
     int *first;       // per candidate: first changed group of scale 0 (H/4 if none), written by the scan for k_sparse_order
     const int *order; // k_sparse_v: candidates of the launch, longest column sweeps first (k_sparse_order); nullptr = as listed
@@ -75,6 +77,15 @@ __device__ __forceinline__ uint32_t sparse_ci(uint32_t lo, uint32_t thr, uint32_
 }
 
 __device__ __forceinline__ uint32_t won_bit(const uint32_t *bm, int px) { return (bm[px >> 5] >> (px & 31)) & 1u; }
+// --dither: colour index of pixel (x0, y0) from a palette_map (ncol = the candidate's colour, ncol + 1 = transparent)
+__device__ __forceinline__ uint32_t maps_ci(const SparseParams &P, const uint8_t *map, bool is_base, int x0, int y0, uint32_t pack_lo) {
+    uint32_t ci = pack_lo >> 24; // ncol + 1 when transparent (pack mode 1)
+    if (ci != (uint32_t)P.ncol + 1u) {
+        ci = (uint32_t)P.tile_pal[(x0 >> 3) + (y0 >> 3) * (P.G.W >> 3)] * (uint32_t)P.sub_size + map[y0 * P.G.W + x0];
+        if (!is_base && ci == P.slot_ci) ci = (uint32_t)P.ncol;
+    }
+    return ci;
+}
 
 __device__ __forceinline__ unsigned long long pair_or_compress(unsigned long long m) { // bit i of result = bit 2i | bit 2i+1 of m
     m = (m | (m >> 1)) & 0x5555555555555555ull;
@@ -287,6 +298,43 @@ __device__ __forceinline__ void sparse_scan_body(const SparseParams &P) {
     scan_publish<16>(P, k, live, mask, xmin, won, P.is_base ? 0 : s_gx[threadIdx.x >> 6][lane]);
 }
 
+// ---- --dither: where does a candidate first differ from B? -----------------------------------------------------
+// Floyd-Steinberg is causal in raster order: the candidate's run is B's run (k_dither MODE 1: the slot's entry out of play)
+// up to the first pixel whose dithered target is nearer to the candidate's colour than to B's choice.  The contested-pixel
+// list holds B's targets and the keys to beat (built from k_dither's record by k_build_plist); one wave per candidate
+// min-reduces the index of the pixels it wins.  From the 4-row group of that pixel on every row differs (the error
+// spreads right and down), so the candidate's changed set is "all groups from there, whole rows".
+__device__ __forceinline__ void dither_first_body(const SparseParams &P) {
+    __shared__ uint32_t s_rgb[kScanTile], s_thr[kScanTile];
+    __shared__ unsigned short s_px[kScanTile]; // W * H <= 65,536
+    const Geom &G = P.G;
+    const int lane = threadIdx.x & 63;
+    const int wi = (int)blockIdx.x * 16 + (threadIdx.x >> 6);
+    const bool live = wi < P.ncand;
+    const int k = P.k0 + (live ? wi : 0);
+    const uint32_t crgb = __float_as_uint(P.cand_tab[8 * (size_t)k + 6]);
+    const int n = *P.plist_count;
+    int first = 0x7fffffff;
+    for (int t0 = 0; t0 < n; t0 += kScanTile) {
+        const int nt = min(kScanTile, n - t0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nt; i += 1024) {
+            const uint4 e = P.plist[t0 + i];
+            s_rgb[i] = e.y; s_thr[i] = e.z; s_px[i] = (unsigned short)e.x;
+        }
+        __syncthreads();
+        if (live)
+            for (int i = lane; i < nt; i += 64)
+                if (red_mean_key(crgb, s_rgb[i]) < s_thr[i]) first = min(first, (int)s_px[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
+    const int H4 = G.H >> 2;
+    const int g0 = first == 0x7fffffff ? H4 : (first / G.W) >> 2;
+    const unsigned long long mask = g0 >= 64 ? 0ull : (~0ull << g0) & (H4 >= 64 ? ~0ull : ((1ull << H4) - 1ull));
+    scan_publish<16>(P, k, live, mask, g0 < H4 ? 0 : G.W, g0 < H4 ? 1 : 0, 0);
+}
+
 // ---- downscale chain + XYB on changed groups only -------------------------------------------------------
 // base: grid.x blocks share the rows of each scale (launched once per scale, P.ncand = scale to do);
 // candidates: one block per candidate walks the scales itself.
@@ -322,7 +370,8 @@ __device__ __forceinline__ void sparse_down_body(const SparseParams &P, int only
                     for (int ix = 0; ix < 2; ix++) {
                         const unsigned long long w = P.pack[(size_t)(2 * y + iy) * G.W + 2 * x + ix];
                         const int px0 = (2 * y + iy) * G.W + 2 * x + ix;
-                        const uint32_t ci = is_base ? ((uint32_t)w >> 24)
+                        const uint32_t ci = P.use_maps ? maps_ci(P, is_base ? P.bmap : P.maps + (size_t)(k - P.k0) * G.W * G.H, is_base, 2 * x + ix, 2 * y + iy, (uint32_t)w)
+                                          : is_base ? ((uint32_t)w >> 24)
                                           : (P.perceptual ? (won_bit(P.bitmap + (size_t)k * (G.W * G.H / 32), px0) ? (uint32_t)P.ncol : ((uint32_t)w >> 24))
                                                           : sparse_ci((uint32_t)w, (uint32_t)(w >> 32), crgb, (uint32_t)P.ncol));
                         sum[0] += s_lin[3 * ci]; sum[1] += s_lin[3 * ci + 1]; sum[2] += s_lin[3 * ci + 2];
@@ -391,7 +440,8 @@ __device__ __forceinline__ void base_down_body(const SparseParams &P) {
         for (int iy = 0; iy < 2; iy++)
 #pragma unroll
             for (int ix = 0; ix < 2; ix++) {
-                const uint32_t ci = (uint32_t)P.pack[(size_t)(Y1 * 2 + iy) * G.W + X1 * 2 + ix] >> 24;
+                const uint32_t lo = (uint32_t)P.pack[(size_t)(Y1 * 2 + iy) * G.W + X1 * 2 + ix];
+                const uint32_t ci = P.use_maps ? maps_ci(P, P.bmap, true, X1 * 2 + ix, Y1 * 2 + iy, lo) : lo >> 24;
                 sum[0] += s_lin[3 * ci]; sum[1] += s_lin[3 * ci + 1]; sum[2] += s_lin[3 * ci + 2];
             }
         const float v[3] = {sum[0] * 0.25f, sum[1] * 0.25f, sum[2] * 0.25f};
@@ -798,8 +848,9 @@ __global__ __launch_bounds__(256, 4) void k_sparse_v(SparseParams P) { if ((int)
 __device__ __forceinline__ void sparse_v_base_body(const SparseParams &P) {
     const int s = (int)blockIdx.y;
     if (s >= P.G.nscales) return;
-    if (s == 0) { if (P.G.sw[0] >= 64) sparse_v_body<true, 1, 1>(P, 0); else sparse_v_body<false, 1, 1>(P, 0); }
-    else if (P.G.sw[s] >= 64) sparse_v_body<true, 0, 1>(P, s);
+    // (scale 0 too reads its map input from the XYB plane B's H pass leaves behind, not from the pack: same values, and with
+    // --dither the pack does not describe B)
+    if (P.G.sw[s] >= 64) sparse_v_body<true, 0, 1>(P, s);
     else sparse_v_body<false, 0, 1>(P, s);
 }
 #undef SNES_HSTEP
@@ -883,6 +934,7 @@ __global__ __launch_bounds__(1024) void k_sparse_order(SparseParams P, int *__re
 // ---- kernel entry points of the bodies above ----
 __global__ __launch_bounds__(256) void k_sparse_scan_lab(SparseParams P) { sparse_scan_lab_body(P); }
 __global__ __launch_bounds__(1024) void k_sparse_scan(SparseParams P) { sparse_scan_body(P); }
+__global__ __launch_bounds__(1024) void k_dither_first(SparseParams P) { dither_first_body(P); }
 __global__ __launch_bounds__(256) void k_sparse_down(SparseParams P, int only_scale) { sparse_down_body(P, only_scale); }
 __global__ __launch_bounds__(256) void k_base_down(SparseParams P) { base_down_body(P); }
 __global__ __launch_bounds__(64) void k_sparse_h(SparseParams P) { sparse_h_body(P); }

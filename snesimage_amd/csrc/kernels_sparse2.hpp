@@ -21,6 +21,7 @@
 //     right of the wave's columns; otherwise the candidate's H pass has not written those columns and they are B's.
 #pragma once
 #include "kernels_sparse.hpp"
+#include "kernels_fast.hpp"
 
 namespace snes {
 
@@ -81,6 +82,9 @@ __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int 
         const uint32_t never = is_base ? 0u : 0xffffffffu; // thr & never == 0 for B: it wins nothing
         const float4 *in1 = reinterpret_cast<const float4 *>(P.img1C4 + G.src_off[s] + (size_t)ch * ns) + y;   // C4: + g*H
         const uint4 *pk = S0 ? reinterpret_cast<const uint4 *>(P.packC4) + 2 * (size_t)y : nullptr;            // + g*2H
+        const bool um = S0 && P.use_maps;
+        const uint32_t *mw = um ? reinterpret_cast<const uint32_t *>(is_base ? P.bmapC4 : P.mapsC4 + (size_t)(k - P.k0) * ns) + y : nullptr; // C4 bytes: word (g*H + y)
+        const uint32_t *sw = um ? reinterpret_cast<const uint32_t *>(P.subC4) + y : nullptr;
         const float4 *in2 = S0 ? nullptr
                                : reinterpret_cast<const float4 *>(P.store + (size_t)k * P.S.cand_stride + P.S.off_xybC[s] + (size_t)j * 12 * W + (size_t)ch * 4 * W) + r; // + g*4
         __syncthreads(); // the previous round's flush has read the bases
@@ -103,7 +107,8 @@ __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int 
         for (int a = 0; a < 5; a++) { r1[a] = make_float4(0.f, 0.f, 0.f, 0.f); r2[a] = r1[a]; }
         uint4 n_pa = make_uint4(0, 0, 0, 0), n_pb = n_pa;
         r1[0] = in1[(size_t)gstart * H];
-        if (S0) { n_pa = pk[(size_t)gstart * H * 2]; n_pb = pk[(size_t)gstart * H * 2 + 1]; } else r2[0] = in2[(size_t)gstart * 4];
+        if (um) { n_pa.x = mw[(size_t)gstart * H]; n_pa.y = sw[(size_t)gstart * H]; }
+        else if (S0) { n_pa = pk[(size_t)gstart * H * 2]; n_pb = pk[(size_t)gstart * H * 2 + 1]; } else r2[0] = in2[(size_t)gstart * 4];
         for (int g0 = gstart; g0 <= G4; g0 += 5) {
 #pragma unroll
             for (int u = 0; u < 5; u++) {
@@ -113,11 +118,16 @@ __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int 
                 const uint4 c_pa = n_pa, c_pb = n_pb;
                 if (g + 1 < G4) {
                     r1[un] = in1[(size_t)(g + 1) * H];
-                    if (S0) { n_pa = pk[(size_t)(g + 1) * H * 2]; n_pb = pk[(size_t)(g + 1) * H * 2 + 1]; } else r2[un] = in2[(size_t)(g + 1) * 4];
+                    if (um) { n_pa.x = mw[(size_t)(g + 1) * H]; n_pa.y = sw[(size_t)(g + 1) * H]; }
+                    else if (S0) { n_pa = pk[(size_t)(g + 1) * H * 2]; n_pb = pk[(size_t)(g + 1) * H * 2 + 1]; } else r2[un] = in2[(size_t)(g + 1) * 4];
                 } else { r1[un] = make_float4(0.f, 0.f, 0.f, 0.f); r2[un] = r1[un]; n_pa = make_uint4(0, 0, 0, 0); n_pb = n_pa; }
                 if (S0 && g < G4) {
                     uint32_t c0, c1, c2, c3;
-                    if (P.perceptual && !is_base) { // four consecutive pixels of row y: four consecutive bits of one bitmap word
+                    if (P.use_maps) { // --dither: the candidate's (or B's) own palette_map; c_pa.x / .y hold the map and subpalette-base words
+                        uint32_t ci[4];
+                        resolve4_maps(c_pa.x, c_pa.y, is_base ? 0xffffffffu : P.slot_ci, (uint32_t)P.ncol, ci);
+                        c0 = ci[0]; c1 = ci[1]; c2 = ci[2]; c3 = ci[3];
+                    } else if (P.perceptual && !is_base) { // four consecutive pixels of row y: four consecutive bits of one bitmap word
                         const int px0 = y * W + (g << 2);
                         const uint32_t b4 = (P.bitmap[(size_t)k * (G.W * G.H / 32) + (px0 >> 5)] >> (px0 & 31)) & 0xfu;
                         c0 = (b4 & 1u) ? (uint32_t)P.ncol : (c_pa.x >> 24); c1 = (b4 & 2u) ? (uint32_t)P.ncol : (c_pa.z >> 24);

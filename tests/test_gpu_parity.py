@@ -547,6 +547,50 @@ def test_sparse_path_equals_dense_path(S, O, seed, variant, perceptual, monkeypa
     sparse.close()
 
 
+@pytest.mark.parametrize("seed,variant", [(0x5EED0000, 0), (0x5EED0001, 1)])
+def test_resumed_dither_equals_full_dither(S, O, seed, variant, monkeypatch):
+    """--dither through causality: B dithered once per slot with the slot's entry out of play, every candidate resumed
+    from B's checkpoint at the 4-row group of the first pixel it takes, the rows from there on scored by the group-sparse
+    kernels — against the round-1 path (every candidate dithered from row 0, dense scoring; SNES_SPARSE=0) bit for bit,
+    and against the oracle for a handful.  Candidates include the incumbent colour, duplicates of neighbours, colours
+    that win nothing and colours that win the very first pixel."""
+    from snesimage_amd.synth import synth_image
+    img = synth_image(seed, variant=variant)
+    monkeypatch.setenv("SNES_SPARSE", "0")
+    dense = S.OptimizedImage(img, 8, 15, dither=True)
+    monkeypatch.delenv("SNES_SPARSE")
+    sparse = S.OptimizedImage(img, 8, 15, dither=True)
+    dense.initialize_tiles()
+    dense.recalculate_palettes()
+    sparse.tile_palettes = dense.tile_palettes
+    sparse.palette = dense.palette
+    sparse.optimize()
+    pal = dense.palette
+    o = O.OracleImage(img, 8, 15, dither=True)
+    o.tile_palettes = dense.tile_palettes
+    o.palette = dense.palette
+    o.optimize()
+    for slot in [(2, 3), (0, 0), (7, 14)]:
+        cand = S.random_candidates(seed, slot[0] * 15 + slot[1], 160)
+        cand[0] = pal[slot[0] * 15 + slot[1]]
+        cand[1] = pal[slot[0] * 15 + (slot[1] + 1) % 15]
+        cand[2] = pal[slot[0] * 15 + (slot[1] + 14) % 15]
+        cand[3] = [0, 0, 0]
+        cand[4] = [31, 31, 31]
+        ed = dense.score_candidates(slot[0], slot[1], cand)
+        es = sparse.score_candidates(slot[0], slot[1], cand)
+        assert np.array_equal(ed, es), (slot, float(np.max(np.abs(ed - es))))
+        assert rel(es[:6], o.score_candidates(slot[0], slot[1], cand[:6])) < REL_ERR
+    # full optimizer calls: the commit adopts the winner's resumed map
+    for i, (p, idx) in enumerate([(3, 3), (3, 4), (0, 0)]):
+        e_d, b_d = dense.step(S.METHOD_RANDOM, p, idx, 0, 9, i, 128)
+        e_s, b_s = sparse.step(S.METHOD_RANDOM, p, idx, 0, 9, i, 128)
+        assert e_d == e_s and np.array_equal(b_d, b_s) and np.array_equal(dense.palette_map, sparse.palette_map)
+    e_o, b_o = None, None
+    dense.close()
+    sparse.close()
+
+
 # ---- one process, several devices: RCCL inside the library ---------------------------------------------
 def test_group_step_over_rccl_equals_plain_step(S, img256):
     """snesimage_group_* with the devices this box has (one): step_begin -> grouped ncclAllReduce(min) -> step_commit must
