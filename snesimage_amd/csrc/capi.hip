@@ -528,7 +528,8 @@ int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si) {
         // wide scales: B rows start at column 0 (list s*kColBuckets) and leave the per-block H checkpoints and the scale-0 XYB plane
         hipLaunchKernelGGL(k_sparse_h2, dim3((unsigned)((G.sh[0] / 4 * 3 + 15) / 16), (unsigned)(P.s_first * kColBuckets)), dim3(64), 0, bs, P);
         if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((G.sh[P.s_first] / 4 * 3 + 15) / 16), (unsigned)(G.nscales * kColBuckets)), dim3(64), 0, bs, P);
-        { SparseParams Pv = P; Pv.s_first = 0; hipLaunchKernelGGL(k_sparse_v_base, dim3(3, (unsigned)G.nscales), dim3(256), 0, bs, Pv); }
+        if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_v_base_narrow, dim3(3, (unsigned)(G.nscales - P.s_first)), dim3(256), 0, bs, P);
+        if (P.s_first > 0) hipLaunchKernelGGL(k_sparse_v2_base, dim3(3, (unsigned)P.s_first), dim3(256), 0, bs, P);
         HIPCHK(hipGetLastError());
         if (sp.side) HIPCHK(hipEventRecord(sp.ev_base_done, bs));
         sp.plist_valid = true;

@@ -193,6 +193,9 @@ __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 template <typename T> __device__ __forceinline__ T ld_at(const void *sbase, uint32_t voff) { return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(sbase) + voff); }
 
+// BASE: the image B itself — every group is its own, the sweep starts at the top with a zero state and leaves the
+// checkpoint records behind (record g: state before group iteration g and pooling sums of rows < 4g-4; record H/4+1: final sums).
+template <bool BASE>
 __device__ __forceinline__ void sparse_v2_body(const SparseParams &P, const int s) {
     __shared__ short s_slot[4][64]; // per wave: group -> slot in the candidate's storage, -1 = B's group
     // tails: xy halves two deep, zw halves three deep, [slot][plane][thread]; the pooling reduction reuses the space
@@ -204,25 +207,27 @@ __device__ __forceinline__ void sparse_v2_body(const SparseParams &P, const int 
     const int t = threadIdx.x, lane = t & 63;
     const int wv = uni(t >> 6);
     const int wpp = W >> 6, ppw = 4 / wpp; // waves per pair, pairs per block
-    const int npairs = P.ncand * 3;
+    const int npairs = BASE ? 3 : P.ncand * 3;
     if ((int)blockIdx.x * ppw >= npairs) return;
     const int ql = wv / wpp, xw = (wv - ql * wpp) << 6; // pair of the wave inside the block, first column of the wave
     const int pair_raw = blockIdx.x * ppw + ql;
     const bool active = pair_raw < npairs;
     const int pair = active ? pair_raw : 0;
-    const int k = uni(P.k0 + (P.order ? P.order[pair / 3] : pair / 3)), ch = pair % 3;
-    const int x = xw + lane;
+    const int k = BASE ? P.base : uni(P.k0 + (P.order ? P.order[pair / 3] : pair / 3)), ch = pair % 3;
     const CandMeta *M = P.meta + k;
-    { // effective slot of every group for this wave: the candidate's own rows only where its H pass has written this wave's columns
+    // Effective slot of every group for this wave: the candidate's own rows only where its H pass has written this wave's
+    // columns (a group whose first changed block lies to the right leaves these columns as B has them).  The wave resumes
+    // from B's checkpoint at ITS first such group — up to there every input of its columns is B's — and takes B's final
+    // sums if there is none.
+    int gs;
+    {
         const int g = lane;
         short sl = -1;
-        if (g < H4) { sl = M->gslot[P.S.goff[s] + g]; if (sl >= 0 && ((int)M->gcb[P.S.goff[s] + g] << 6) > xw) sl = -1; }
-        s_slot[wv][lane] = sl;
+        if (!BASE && g < H4) { sl = M->gslot[P.S.goff[s] + g]; if (sl >= 0 && ((int)M->gcb[P.S.goff[s] + g] << 6) > xw) sl = -1; }
+        s_slot[wv][lane] = sl; // (B: every group is read from B's own storage, which is what slot -1 selects)
+        const unsigned long long own = __ballot(sl >= 0);
+        gs = BASE ? 0 : uni(own ? __ffsll((long long)own) - 1 : H4 + 1);
     }
-    const int ng = uni(M->ngroups[s]);
-    const int cmin = uni((M->xmin >> s) - 5); // columns <= cmin see only unchanged inputs
-    const bool skip = ng == 0 || x <= cmin;
-    const int gs = uni(__all(skip) ? H4 + 1 : (int)M->glist[P.S.goff[s]]); // a skipping wave takes B's final sums
     __syncthreads();
 
     const size_t ns = (size_t)W * H;
@@ -243,7 +248,16 @@ __device__ __forceinline__ void sparse_v2_body(const SparseParams &P, const int 
     const float d1_0 = P.K.d1[0], d1_1 = P.K.d1[1], d1_2 = P.K.d1[2];
     float sa[3][3], sb[3][3];
     double acc[6];
-    { // checkpoint record gs: ckf[s][ch][g][18][W], cka[s][ch][g][6][W]
+    float *ck_f = P.ckf + P.S.off_ckf[s] + ((size_t)ch * (H4 + 2)) * 18 * W + xw + lane; // B: record being written
+    double *ck_a = P.cka + P.S.off_cka[s] + ((size_t)ch * (H4 + 2)) * 6 * W + xw + lane;
+    if (BASE) {
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) { sa[p][q] = 0.0f; sb[p][q] = 0.0f; }
+#pragma unroll
+        for (int q = 0; q < 6; q++) acc[q] = 0.0;
+    } else { // checkpoint record gs: ckf[s][ch][g][18][W], cka[s][ch][g][6][W]
         const float *cf = P.ckf + P.S.off_ckf[s] + ((size_t)ch * (H4 + 2) + gs) * 18 * W + xw;
         const double *ca = P.cka + P.S.off_cka[s] + ((size_t)ch * (H4 + 2) + gs) * 6 * W + xw;
 #pragma unroll
@@ -279,6 +293,12 @@ __device__ __forceinline__ void sparse_v2_body(const SparseParams &P, const int 
     int r2 = 0, r3 = 0; // (g - gs) mod 2, mod 3: wave-uniform ring slots
 #define SNES_V2GROUP(CUR, NXT)                                                                                                \
     {                                                                                                                         \
+        if (BASE && active) { /* record g */                                                                                  \
+            _Pragma("unroll") for (int p = 0; p < 3; p++)                                                                     \
+                _Pragma("unroll") for (int q = 0; q < 3; q++) { ck_f[(size_t)(p * 6 + q) * W] = sa[p][q]; ck_f[(size_t)(p * 6 + 3 + q) * W] = sb[p][q]; } \
+            _Pragma("unroll") for (int q = 0; q < 6; q++) ck_a[(size_t)q * W] = acc[q];                                       \
+            ck_f += (size_t)18 * W; ck_a += (size_t)6 * W;                                                                    \
+        }                                                                                                                     \
         if (g + 1 < H4) { const float *hp = hbase(g + 1); NXT[0] = ld_at<float4>(hp, l16); NXT[1] = ld_at<float4>(hp + W4, l16); NXT[2] = ld_at<float4>(hp + 2 * W4, l16); } \
         else { NXT[0] = zero4; NXT[1] = zero4; NXT[2] = zero4; }                                                              \
         /* inputs of the maps of row group g-1, consumed after the recurrence steps below */                                  \
@@ -318,6 +338,10 @@ __device__ __forceinline__ void sparse_v2_body(const SparseParams &P, const int 
         SNES_V2GROUP(bufB, bufA)
     }
 #undef SNES_V2GROUP
+    if (BASE && active) { // final record (H4 + 1): the pooling sums of the whole column
+#pragma unroll
+        for (int q = 0; q < 6; q++) ck_a[(size_t)q * W] = acc[q];
+    }
     __syncthreads(); // the tail ring is dead: its space becomes the reduction scratch
 #pragma unroll
     for (int q = 0; q < 6; q++) red[t][q] = active ? acc[q] : 0.0;
@@ -346,6 +370,11 @@ __device__ __forceinline__ void sparse_h2_dispatch(const SparseParams &P) {
     if (s == 0) sparse_h2_body<true>(P, list); else sparse_h2_body<false>(P, list);
 }
 __global__ __launch_bounds__(64) void k_sparse_h2(SparseParams P) { sparse_h2_dispatch(P); }
-__global__ __launch_bounds__(256, 4) void k_sparse_v2(SparseParams P) { if ((int)blockIdx.y < P.G.nscales && P.G.sw[blockIdx.y] >= 64) sparse_v2_body(P, (int)blockIdx.y); }
+__global__ __launch_bounds__(256, 4) void k_sparse_v2(SparseParams P) { if ((int)blockIdx.y < P.G.nscales && P.G.sw[blockIdx.y] >= 64) sparse_v2_body<false>(P, (int)blockIdx.y); }
+// B: the wide scales in this body (grid.y = scale), the narrow ones in the general one (grid.y = scale - s_first), two launches:
+// one kernel holding both bodies would take the larger register allocation for every block
+__global__ __launch_bounds__(256) void k_sparse_v2_base(SparseParams P) { if ((int)blockIdx.y < P.G.nscales && P.G.sw[blockIdx.y] >= 64) sparse_v2_body<true>(P, (int)blockIdx.y); }
+__device__ __forceinline__ void sparse_v_base_narrow_dispatch(const SparseParams &P) { const int s = (int)blockIdx.y + P.s_first; if (s < P.G.nscales) sparse_v_body<false, 0, 1>(P, s); }
+__global__ __launch_bounds__(256, 1) void k_sparse_v_base_narrow(SparseParams P) { sparse_v_base_narrow_dispatch(P); }
 
 } // namespace snes
