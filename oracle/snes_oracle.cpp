@@ -6,6 +6,7 @@
 // multiply-adds that the restated Rust code spells `mul_add` are explicit fmaf()/fma() calls;
 // nothing else may be contracted.
 #include "snes_oracle.h"
+#include "../include/ssimulacra2_constants.h" // the one copy of the restated crates' constants (shared with the product)
 #include "det_math.h"
 
 #include <algorithm>
@@ -289,8 +290,8 @@ struct BlurConsts {
     float vert_mul_in[3], vert_mul_prev[3];     // vertical: n2, d1
     double fir[9];                              // equivalent zero-padded FIR taps h[-4..4] (binary64)
     BlurConsts() {
-        const double SIGMA = 1.5, PI = 3.14159265358979323846;
-        double radius_d = std::round(std::fma(3.2795, SIGMA, 0.2546)); // (57), N = 5
+        const double SIGMA = SSIM2_BLUR_SIGMA, PI = 3.14159265358979323846;
+        double radius_d = std::round(std::fma(SSIM2_BLUR_RADIUS_A, SIGMA, SSIM2_BLUR_RADIUS_B)); // (57), N = 5
         radius = (int)radius_d;
         double pi_div_2r = PI / (2.0 * radius_d);
         double omega[3] = {pi_div_2r, 3.0 * pi_div_2r, 5.0 * pi_div_2r};
@@ -453,11 +454,11 @@ void downscale_by_2(const Img3 &in, Img3 &out) {
 }
 // yuvxyb linear_rgb_to_xyb + ssimulacra2 make_positive_xyb, planar output
 inline void linear_rgb_to_positive_xyb(float r, float g, float b, float *X, float *Y, float *B) {
-    const float K_M02 = 0.078f, K_M00 = 0.30f, K_M01 = 1.0f - K_M02 - K_M00;
-    const float K_M12 = 0.078f, K_M10 = 0.23f, K_M11 = 1.0f - K_M12 - K_M10;
-    const float K_M20 = 0.24342268924547819f, K_M21 = 0.20476744424496821f, K_M22 = 1.0f - K_M20 - K_M21;
-    const float K_B0 = 0.0037930732552754493f;
-    const float K_B0_ROOT = 0.1559542025327239180319220163705f;
+    const float K_M02 = SSIM2_OPSIN_M02, K_M00 = SSIM2_OPSIN_M00, K_M01 = 1.0f - K_M02 - K_M00;
+    const float K_M12 = SSIM2_OPSIN_M12, K_M10 = SSIM2_OPSIN_M10, K_M11 = 1.0f - K_M12 - K_M10;
+    const float K_M20 = SSIM2_OPSIN_M20, K_M21 = SSIM2_OPSIN_M21, K_M22 = 1.0f - K_M20 - K_M21;
+    const float K_B0 = SSIM2_OPSIN_BIAS;
+    const float K_B0_ROOT = SSIM2_OPSIN_BIAS_CBRT;
     float m0 = fmaf(K_M00, r, fmaf(K_M01, g, fmaf(K_M02, b, K_B0)));
     float m1 = fmaf(K_M10, r, fmaf(K_M11, g, fmaf(K_M12, b, K_B0)));
     float m2 = fmaf(K_M20, r, fmaf(K_M21, g, fmaf(K_M22, b, K_B0)));
@@ -467,9 +468,9 @@ inline void linear_rgb_to_positive_xyb(float r, float g, float b, float *X, floa
     m0 = det_cbrtf(m0) - K_B0_ROOT; m1 = det_cbrtf(m1) - K_B0_ROOT; m2 = det_cbrtf(m2) - K_B0_ROOT;
     float x = 0.5f * (m0 - m1), y = 0.5f * (m0 + m1), bb = m2;
     // make_positive_xyb
-    *B = (bb - y) + 0.55f;
-    *X = fmaf(x, 14.0f, 0.42f);
-    *Y = y + 0.01f;
+    *B = (bb - y) + SSIM2_POS_B_OFFSET;
+    *X = fmaf(x, SSIM2_POS_X_SCALE, SSIM2_POS_X_OFFSET);
+    *Y = y + SSIM2_POS_Y_OFFSET;
 }
 void to_positive_xyb(const Img3 &lin, Img3 &xyb) {
     xyb.resize(lin.w, lin.h);
@@ -477,23 +478,7 @@ void to_positive_xyb(const Img3 &lin, Img3 &xyb) {
     for (size_t i = 0; i < n; i++) linear_rgb_to_positive_xyb(lin.p[0][i], lin.p[1][i], lin.p[2][i], &xyb.p[0][i], &xyb.p[1][i], &xyb.p[2][i]);
 }
 
-const double SSIM2_WEIGHT[108] = {
-    0.0, 0.0007376606707406586, 0.0, 0.0, 0.0007793481682867309, 0.0, 0.0, 0.0004371155730107379, 0.0,
-    1.1041726426657346, 0.00066284834129271, 0.00015231632783718752, 0.0, 0.0016406437456599754, 0.0,
-    1.8422455520539298, 11.441172603757666, 0.0, 0.0007989109436015163, 0.000176816438078653, 0.0,
-    1.8787594979546387, 10.94906990605142, 0.0, 0.0007289346991508072, 0.9677937080626833, 0.0,
-    0.00014003424285435884, 0.9981766977854967, 0.00031949755934435053, 0.0004550992113792063, 0.0, 0.0,
-    0.0013648766163243398, 0.0, 0.0, 0.0, 0.0, 0.0, 7.466890328078848, 0.0, 17.445833984131262,
-    0.0006235601634041466, 0.0, 0.0, 6.683678146179332, 0.00037724407979611296, 1.027889937768264,
-    225.20515300849274, 0.0, 0.0, 19.213238186143016, 0.0011401524586618361, 0.001237755635509985,
-    176.39317598450694, 0.0, 0.0, 24.43300999870476, 0.28520802612117757, 0.0004485436923833408,
-    0.0, 0.0, 0.0, 34.77906344483772, 44.835625328877896, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0,
-    0.0, 0.0008680556573291698, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0005313191874358747, 0.0,
-    0.00016533814161379112, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0004179171803251336, 0.0017290828234722833,
-    0.0, 0.0020827005846636437, 0.0, 0.0, 8.826982764996862, 23.19243343998926, 0.0,
-    95.1080498811086, 0.9863978034400682, 0.9834382792465353, 0.0012286405048278493,
-    171.2667255897307, 0.9807858872435379, 0.0, 0.0, 0.0, 0.0005130064588990679, 0.0,
-    0.00010854057858411537};
+const double SSIM2_WEIGHT[108] = SSIM2_WEIGHTS; // include/ssimulacra2_constants.h
 static_assert(sizeof(SSIM2_WEIGHT) / sizeof(double) == 108, "weight table must hold 108 entries");
 
 struct ScaleStats { double avg_ssim[6]; double avg_edgediff[12]; };
@@ -525,7 +510,7 @@ void build_src_pyramid(const Img3 &lin0, int blur_mode, SrcPyramid &P) {
 
 // ssim_map + edge_diff_map of one scale
 void scale_maps(const SrcScale &S, const Img3 &img2, const Img3 &mu2, const Img3 &s22, const Img3 &s12, ScaleStats &out) {
-    const float C2 = 0.0009f;
+    const float C2 = SSIM2_C2;
     const int width = S.w, height = S.h;
     const double one_per_pixels = 1.0 / (double)((size_t)width * height);
     for (int c = 0; c < 3; c++) {
@@ -576,10 +561,10 @@ double msssim_score(const std::vector<ScaleStats> &scales) {
                 ssim = std::fma(SSIM2_WEIGHT[i], std::fabs(scale.avg_edgediff[c * 4 + n]), ssim); i++;
                 ssim = std::fma(SSIM2_WEIGHT[i], std::fabs(scale.avg_edgediff[c * 4 + n + 2]), ssim); i++;
             }
-    ssim *= 0.9562382616834844;
-    ssim = std::fma(6.248496625763138e-5 * ssim * ssim, ssim, std::fma(2.326765642916932, ssim, -0.020884521182843837 * ssim * ssim));
-    if (ssim > 0.0) ssim = std::fma(std::pow(ssim, 0.6276336467831387), -10.0, 100.0);
-    else ssim = 100.0;
+    ssim *= SSIM2_SCORE_SCALE;
+    ssim = std::fma(SSIM2_SCORE_C3 * ssim * ssim, ssim, std::fma(SSIM2_SCORE_C1, ssim, SSIM2_SCORE_C2 * ssim * ssim));
+    if (ssim > 0.0) ssim = std::fma(std::pow(ssim, SSIM2_SCORE_EXP), SSIM2_SCORE_GAIN, SSIM2_SCORE_MAX);
+    else ssim = SSIM2_SCORE_MAX;
     return ssim;
 }
 

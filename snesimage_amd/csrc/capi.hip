@@ -39,8 +39,8 @@ int32_t fail(int32_t code, const std::string &msg) { g_err = msg; return code; }
 
 // ssimulacra2 build.rs: recursive-Gaussian constants for sigma = 1.5 (binary64, then f32)
 BlurK make_blur_constants() {
-    const double SIGMA = 1.5, PI = 3.14159265358979323846;
-    const double radius = std::round(std::fma(3.2795, SIGMA, 0.2546));
+    const double SIGMA = SSIM2_BLUR_SIGMA, PI = 3.14159265358979323846;
+    const double radius = std::round(std::fma(SSIM2_BLUR_RADIUS_A, SIGMA, SSIM2_BLUR_RADIUS_B));
     const double w0 = PI / (2.0 * radius);
     const double omega[3] = {w0, 3.0 * w0, 5.0 * w0};
     const double p1 = 1.0 / std::tan(0.5 * omega[0]), p3 = -1.0 / std::tan(0.5 * omega[1]), p5 = 1.0 / std::tan(0.5 * omega[2]);

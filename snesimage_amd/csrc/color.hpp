@@ -3,6 +3,7 @@
 // :1080-1100 (distances); third-party arithmetic per SURVEY App. A (palette 0.7.6, yuvxyb 0.4.2).
 #pragma once
 #include "dmath.hpp"
+#include "../../include/ssimulacra2_constants.h" // the one copy of the restated crates' constants (shared with the oracle)
 
 namespace snes {
 
@@ -132,11 +133,11 @@ SNES_HD float ciede2000(Lab c1, Lab c2) {
 
 // ---- yuvxyb 0.4.2 linear RGB -> XYB, then ssimulacra2's make_positive_xyb ----------------------
 SNES_HD void linear_to_positive_xyb(float r, float g, float b, float &X, float &Y, float &B) {
-    const float m02 = 0.078f, m00 = 0.30f, m01 = 1.0f - m02 - m00;
-    const float m12 = 0.078f, m10 = 0.23f, m11 = 1.0f - m12 - m10;
-    const float m20 = 0.24342268924547819f, m21 = 0.20476744424496821f, m22 = 1.0f - m20 - m21;
-    const float b0 = 0.0037930732552754493f;
-    const float b0_root = 0.1559542025327239180319220163705f;
+    const float m02 = SSIM2_OPSIN_M02, m00 = SSIM2_OPSIN_M00, m01 = 1.0f - m02 - m00; // include/ssimulacra2_constants.h
+    const float m12 = SSIM2_OPSIN_M12, m10 = SSIM2_OPSIN_M10, m11 = 1.0f - m12 - m10;
+    const float m20 = SSIM2_OPSIN_M20, m21 = SSIM2_OPSIN_M21, m22 = 1.0f - m20 - m21;
+    const float b0 = SSIM2_OPSIN_BIAS;
+    const float b0_root = SSIM2_OPSIN_BIAS_CBRT;
     float a0 = fmaf(m00, r, fmaf(m01, g, fmaf(m02, b, b0)));
     float a1 = fmaf(m10, r, fmaf(m11, g, fmaf(m12, b, b0)));
     float a2 = fmaf(m20, r, fmaf(m21, g, fmaf(m22, b, b0)));
@@ -145,9 +146,9 @@ SNES_HD void linear_to_positive_xyb(float r, float g, float b, float &X, float &
     if (a2 < 0.0f) a2 = 0.0f;
     a0 = d_cbrtf(a0) - b0_root; a1 = d_cbrtf(a1) - b0_root; a2 = d_cbrtf(a2) - b0_root;
     float x = 0.5f * (a0 - a1), y = 0.5f * (a0 + a1);
-    B = (a2 - y) + 0.55f;
-    X = fmaf(x, 14.0f, 0.42f);
-    Y = y + 0.01f;
+    B = (a2 - y) + SSIM2_POS_B_OFFSET;
+    X = fmaf(x, SSIM2_POS_X_SCALE, SSIM2_POS_X_OFFSET);
+    Y = y + SSIM2_POS_Y_OFFSET;
 }
 
 } // namespace snes

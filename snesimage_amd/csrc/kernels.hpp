@@ -21,7 +21,7 @@
 
 namespace snes {
 
-constexpr int kMaxScales = 6;
+constexpr int kMaxScales = SSIM2_NUM_SCALES;
 constexpr int kBlurRadius = 5; // N of ssimulacra2's recursive Gaussian at sigma = 1.5
 
 // Blocked layouts used by the wide-access kernels of kernels_fast.hpp
@@ -44,23 +44,7 @@ struct Geom {
     long long src_off[kMaxScales]; // same offset used in img1, img1T, mu1, s11 (each 3*N_s at scale s)
 };
 
-__device__ __constant__ double kSsim2Weight[108] = {
-    0.0, 0.0007376606707406586, 0.0, 0.0, 0.0007793481682867309, 0.0, 0.0, 0.0004371155730107379, 0.0,
-    1.1041726426657346, 0.00066284834129271, 0.00015231632783718752, 0.0, 0.0016406437456599754, 0.0,
-    1.8422455520539298, 11.441172603757666, 0.0, 0.0007989109436015163, 0.000176816438078653, 0.0,
-    1.8787594979546387, 10.94906990605142, 0.0, 0.0007289346991508072, 0.9677937080626833, 0.0,
-    0.00014003424285435884, 0.9981766977854967, 0.00031949755934435053, 0.0004550992113792063, 0.0, 0.0,
-    0.0013648766163243398, 0.0, 0.0, 0.0, 0.0, 0.0, 7.466890328078848, 0.0, 17.445833984131262,
-    0.0006235601634041466, 0.0, 0.0, 6.683678146179332, 0.00037724407979611296, 1.027889937768264,
-    225.20515300849274, 0.0, 0.0, 19.213238186143016, 0.0011401524586618361, 0.001237755635509985,
-    176.39317598450694, 0.0, 0.0, 24.43300999870476, 0.28520802612117757, 0.0004485436923833408,
-    0.0, 0.0, 0.0, 34.77906344483772, 44.835625328877896, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0,
-    0.0, 0.0008680556573291698, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0005313191874358747, 0.0,
-    0.00016533814161379112, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0004179171803251336, 0.0017290828234722833,
-    0.0, 0.0020827005846636437, 0.0, 0.0, 8.826982764996862, 23.19243343998926, 0.0,
-    95.1080498811086, 0.9863978034400682, 0.9834382792465353, 0.0012286405048278493,
-    171.2667255897307, 0.9807858872435379, 0.0, 0.0, 0.0, 0.0005130064588990679, 0.0,
-    0.00010854057858411537};
+__device__ __constant__ double kSsim2Weight[108] = SSIM2_WEIGHTS; // include/ssimulacra2_constants.h
 
 // ------------------------------------------------------------------------------------------------
 // Palette tables: per colour index the linear RGB and positive-XYB triple of its 8-bit expansion.
@@ -422,8 +406,8 @@ __device__ __forceinline__ void maps_accumulate(double (&acc)[6], float m1, floa
     const float mu22 = m2 * m2, mu12 = m1 * m2;
     const float mu_diff = m1 - m2;
     const float num_m = fmaf(mu_diff, -mu_diff, 1.0f);
-    const float num_s = fmaf(2.0f, v12 - mu12, 0.0009f);
-    const float denom_s = sd1 + (v22 - mu22) + 0.0009f;
+    const float num_s = fmaf(2.0f, v12 - mu12, SSIM2_C2);
+    const float denom_s = sd1 + (v22 - mu22) + SSIM2_C2;
     double d = 1.0 - (double)((num_m * num_s) / denom_s);
     d = d > 0.0 ? d : 0.0;
     acc[0] += d;
@@ -723,10 +707,10 @@ __device__ __forceinline__ void final_score_body(const double *__restrict__ part
                 ssim = fma(kSsim2Weight[i], fabs(avg_edge[n + 2]), ssim); i++;
             }
         }
-    ssim *= 0.9562382616834844;
-    ssim = fma(6.248496625763138e-5 * ssim * ssim, ssim, fma(2.326765642916932, ssim, -0.020884521182843837 * ssim * ssim));
-    if (ssim > 0.0) ssim = fma(pow(ssim, 0.6276336467831387), -10.0, 100.0);
-    else ssim = 100.0;
+    ssim *= SSIM2_SCORE_SCALE;
+    ssim = fma(SSIM2_SCORE_C3 * ssim * ssim, ssim, fma(SSIM2_SCORE_C1, ssim, SSIM2_SCORE_C2 * ssim * ssim));
+    if (ssim > 0.0) ssim = fma(pow(ssim, SSIM2_SCORE_EXP), SSIM2_SCORE_GAIN, SSIM2_SCORE_MAX);
+    else ssim = SSIM2_SCORE_MAX;
     errors[(size_t)err_offset + (size_t)c * err_stride] = 100.0 - ssim;
 }
 

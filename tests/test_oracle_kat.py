@@ -142,16 +142,21 @@ def test_error_nonnegative_and_transparent_counts(O, img256, img256_alpha):
     assert not rgba[96:160, 96:160].any()
 
 
-def test_ssim2_weights_count():
-    # the 108 weights are transcribed once in the oracle and once in the kernels; they must agree
+def test_ssim2_constants_live_in_one_header():
+    """the restated crates' constants (108 weights, opsin matrix, blur, C2, score polynomial) sit in ONE
+    header that both the oracle and the product include; neither side keeps a literal copy."""
     import re
-    a = open("oracle/snes_oracle.cpp").read()
-    b = open("snesimage_amd/csrc/kernels.hpp").read()
-    wa = re.search(r"SSIM2_WEIGHT\[108\] = \{(.*?)\};", a, re.S).group(1)
-    wb = re.search(r"kSsim2Weight\[108\] = \{(.*?)\};", b, re.S).group(1)
-    fa = [float(t) for t in wa.replace("\n", " ").split(",") if t.strip()]
-    fb = [float(t) for t in wb.replace("\n", " ").split(",") if t.strip()]
-    assert len(fa) == 108 and fa == fb
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "ssimulacra2_constants.h")).read()
+    w = re.search(r"#define SSIM2_WEIGHTS \{(.*?)\}", hdr, re.S).group(1).replace("\\", " ")
+    vals = [float(t) for t in w.replace("\n", " ").split(",") if t.strip()]
+    assert len(vals) == 108 and abs(sum(vals) - 888.3148365876134) < 1e-9  # checksum of the transcription
+    a = open(os.path.join(root, "oracle", "snes_oracle.cpp")).read()
+    b = "".join(open(os.path.join(root, "snesimage_amd", "csrc", f)).read() for f in ("kernels.hpp", "color.hpp", "capi.hip"))
+    for text in (a, b):
+        assert "ssimulacra2_constants.h" in text and "SSIM2_WEIGHTS" in text
+        for literal in ("0.9562382616834844", "0.0037930732552754493", "225.20515300849274", "0.24342268924547819", "3.2795"):
+            assert literal not in text, literal
 
 
 # ---- KAT 7: JSON shape (lib.rs:579-625) ------------------------------------------------------------
