@@ -303,7 +303,7 @@ __device__ __forceinline__ void sparse_scan_body(const SparseParams &P) {
 // up to the first pixel whose dithered target is nearer to the candidate's colour than to B's choice.  The contested-pixel
 // list holds B's targets and the keys to beat (built from k_dither's record by k_build_plist); one wave per candidate
 // min-reduces the index of the pixels it wins.  From the 4-row group of that pixel on every row differs (the error
-// spreads right and down), so the candidate's changed set is "all groups from there, whole rows".
+// may spread right and down): k_dither (MODE 2) re-runs those rows, k_dither_diff then finds what actually changed.
 __device__ __forceinline__ void dither_first_body(const SparseParams &P) {
     __shared__ uint32_t s_rgb[kScanTile], s_thr[kScanTile];
     __shared__ unsigned short s_px[kScanTile]; // W * H <= 65,536
@@ -329,10 +329,41 @@ __device__ __forceinline__ void dither_first_body(const SparseParams &P) {
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
-    const int H4 = G.H >> 2;
-    const int g0 = first == 0x7fffffff ? H4 : (first / G.W) >> 2;
-    const unsigned long long mask = g0 >= 64 ? 0ull : (~0ull << g0) & (H4 >= 64 ? ~0ull : ((1ull << H4) - 1ull));
-    scan_publish<16>(P, k, live, mask, g0 < H4 ? 0 : G.W, g0 < H4 ? 1 : 0, 0);
+    if (live && lane == 0) P.first[k] = first == 0x7fffffff ? (G.H >> 2) : (first / G.W) >> 2; // k_dither (MODE 2) resumes there
+}
+
+// ---- --dither: what did the resumed run change? -------------------------------------------------------------------
+// The error a changed pixel injects is diffused with a total weight of 0.8 per row, so it fades: away from the pixels the
+// candidate takes, its resumed run soon chooses what B chose.  The score depends on the picture only, so the changed set
+// of the group-sparse scorer is simply where the two palette_maps differ (a pixel on the slot's index always does: B never
+// uses it).  One wave per candidate, one row per iteration (lane = four pixels); publishes like the scans.
+__device__ __forceinline__ void dither_diff_body(const SparseParams &P) {
+    __shared__ int s_gx[16][64];
+    const Geom &G = P.G;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wi = (int)blockIdx.x * 16 + w;
+    const bool live = wi < P.ncand;
+    const int k = P.k0 + (live ? wi : 0);
+    s_gx[w][lane] = 0x7fff;
+    unsigned long long mask = 0ull; int xmin = G.W, won = 0;
+    if (live) {
+        const uint32_t *mc = reinterpret_cast<const uint32_t *>(P.maps + (size_t)(k - P.k0) * G.W * G.H), *mb = reinterpret_cast<const uint32_t *>(P.bmap);
+        const int y0 = min(4 * P.first[k], G.H);
+        for (int y = y0; y < G.H; y++) { // W = 256: 64 words per row
+            const uint32_t d = mc[y * 64 + lane] ^ mb[y * 64 + lane];
+            const unsigned long long m = __ballot(d != 0u);
+            if (m) {
+                const int l0 = __ffsll((long long)m) - 1;
+                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, l0);
+                const int x = 4 * l0 + ((__ffs((int)d0) - 1) >> 3);
+                if (lane == 0) s_gx[w][y >> 2] = min(s_gx[w][y >> 2], x);
+                mask |= 1ull << (y >> 2);
+                xmin = min(xmin, x);
+                won += __popcll(m); // (words, not pixels: only a statistic)
+            }
+        }
+    }
+    scan_publish<16>(P, k, live, mask, xmin, won, s_gx[w][lane]);
 }
 
 // ---- downscale chain + XYB on changed groups only -------------------------------------------------------
@@ -935,6 +966,7 @@ __global__ __launch_bounds__(1024) void k_sparse_order(SparseParams P, int *__re
 __global__ __launch_bounds__(256) void k_sparse_scan_lab(SparseParams P) { sparse_scan_lab_body(P); }
 __global__ __launch_bounds__(1024) void k_sparse_scan(SparseParams P) { sparse_scan_body(P); }
 __global__ __launch_bounds__(1024) void k_dither_first(SparseParams P) { dither_first_body(P); }
+__global__ __launch_bounds__(1024) void k_dither_diff(SparseParams P) { dither_diff_body(P); }
 __global__ __launch_bounds__(256) void k_sparse_down(SparseParams P, int only_scale) { sparse_down_body(P, only_scale); }
 __global__ __launch_bounds__(256) void k_base_down(SparseParams P) { base_down_body(P); }
 __global__ __launch_bounds__(64) void k_sparse_h(SparseParams P) { sparse_h_body(P); }
