@@ -131,6 +131,13 @@ int32_t snesimage_batch_step_async(snesimage_batch *batch, uint32_t method, uint
                                    uint32_t n_random);
 int32_t snesimage_batch_sync(snesimage_batch *batch);
 
+/* Dynamic tile -> subpalette reassignment — NOT a reference method: /root/reference/TODO.md:36-37 lists it as missing ("no
+ * attempt is made to reassign tiles dynamically if it could improve the overall result").  Every tile with an opaque pixel
+ * moves to the subpalette with the strictly smallest cost, cost(p) = sum over the tile's opaque pixels (raster order) of the
+ * distance optimize() minimises (lib.rs:1080-1100) to the nearest entry of subpalette p, in binary64; ties keep the current
+ * subpalette, then the lower index.  Palettes are kept; optimize() re-runs if a tile moved.  *moved = tiles moved. */
+int32_t snesimage_reassign_tiles(snesimage_ctx *ctx, uint32_t *moved);
+
 /* State access (the reference mutates these fields directly: lib.rs:1015 and the GUI). */
 int32_t snesimage_get_tile_palettes(snesimage_ctx *ctx, uint8_t *out /*1024*/);
 int32_t snesimage_set_tile_palettes(snesimage_ctx *ctx, const uint8_t *in /*1024*/);

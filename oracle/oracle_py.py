@@ -48,6 +48,7 @@ def lib():
         for name in ("oracle_initialize_tiles", "oracle_recalculate_palettes", "oracle_optimize"):
             getattr(L, name).argtypes = [C.c_void_p]
         L.oracle_error.argtypes = [C.c_void_p, _f64p]
+        L.oracle_reassign_tiles.argtypes = [C.c_void_p, _u32p]
         L.oracle_score_candidates.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, _u8p, C.c_uint32, _f64p, _u8p]
         L.oracle_step.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                   C.c_uint64, C.c_uint32, _f64p, _u8p]
@@ -276,6 +277,12 @@ class OracleImage:
         out = C.c_double(0)
         self._chk(self._L.oracle_error(self._c, C.byref(out)))
         return out.value
+
+    def reassign_tiles(self):
+        """Move every tile to the subpalette that reproduces it best (not in the reference: TODO.md:36-37); tiles moved."""
+        moved = C.c_uint32(0)
+        self._chk(self._L.oracle_reassign_tiles(self._c, C.byref(moved)))
+        return moved.value
 
     def score_candidates(self, palette, index, rgb5, want_maps=False):
         cand = _u8(rgb5).reshape(-1, 3)

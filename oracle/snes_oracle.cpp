@@ -754,6 +754,44 @@ void oracle_set_cache_source(oracle_ctx *c, int on) { c->cache_source = on; }
 void oracle_set_blur_mode(oracle_ctx *c, int mode) { c->blur_mode = mode; }
 
 int oracle_optimize(oracle_ctx *c) { optimize(c); return 0; }
+
+// Dynamic tile -> subpalette reassignment: NOT in the reference — /root/reference/TODO.md:36-37 lists it as missing ("no
+// attempt is made to reassign tiles dynamically ... The initial guess is probably not optimal").  Definition used by the
+// oracle and the product alike: for every tile with at least one opaque pixel, cost(p) = sum over its opaque pixels, in
+// raster order inside the tile (y outer, x inner), of the distance optimize() minimises (lib.rs:1080-1100) between the pixel
+// and the nearest entry of subpalette p (first minimum wins, lib.rs:788-791), accumulated in binary64.  The tile moves
+// to the subpalette with the strictly smallest cost, scanning p upwards from its current one's cost (ties keep the current
+// subpalette, then the lower index).  Palettes are kept; optimize() re-runs if any tile moved.  Returns the tiles moved.
+int oracle_reassign_tiles(oracle_ctx *c, uint32_t *moved_out) {
+    uint32_t moved = 0;
+    for (uint32_t ty = 0; ty < c->height_in_tiles(); ty++)
+        for (uint32_t tx = 0; tx < c->width_in_tiles(); tx++) {
+            std::vector<double> cost(c->sub_count, 0.0);
+            bool any = false;
+            for (uint32_t y = 0; y < 8; y++)
+                for (uint32_t x = 0; x < 8; x++) {
+                    const uint8_t *oc = c->px(tx * 8 + x, ty * 8 + y);
+                    if (oc[3] == 0) continue;
+                    any = true;
+                    const double target[3] = {(double)oc[0], (double)oc[1], (double)oc[2]};
+                    const Rgb8 tc{oc[0], oc[1], oc[2]};
+                    for (uint32_t p = 0; p < c->sub_count; p++) {
+                        const uint8_t *entries = &c->colors[3 * (size_t)p * c->sub_size];
+                        const uint32_t j = closest_color_index(entries, c->sub_size, target, c->perceptual);
+                        const Rgb8 color = snes_as_rgba(entries + 3 * j);
+                        cost[p] = cost[p] + (c->perceptual ? distance_cielab(color, tc) : distance_red_mean(color, tc));
+                    }
+                }
+            if (!any) continue;
+            uint8_t &cur = c->tile_palettes[ty * c->width_in_tiles() + tx];
+            uint32_t best = cur;
+            for (uint32_t p = 0; p < c->sub_count; p++) if (cost[p] < cost[best]) best = p;
+            if (best != cur) { cur = (uint8_t)best; moved++; }
+        }
+    if (moved) optimize(c);
+    if (moved_out) *moved_out = moved;
+    return 0;
+}
 int oracle_error(oracle_ctx *c, double *out) { *out = error_of(c); return 0; }
 
 // lib.rs:79-189

@@ -39,6 +39,7 @@ int oracle_initialize_tiles(oracle_ctx *);       /* lib.rs:79-189  */
 int oracle_recalculate_palettes(oracle_ctx *);   /* lib.rs:407-415 */
 int oracle_optimize(oracle_ctx *);               /* lib.rs:425-501 */
 int oracle_error(oracle_ctx *, double *out);     /* lib.rs:503-548 */
+int oracle_reassign_tiles(oracle_ctx *, uint32_t *moved); /* not in the reference (TODO.md:36-37); definition in snes_oracle.cpp */
 
 /* Body of lib.rs:205-220 for an explicit candidate list: for each k, entry (palette,index) :=
  * rgb5[3k..3k+2] (raw 5-bit r,g,b), optimize(), error().  The palette entry and palette_map are

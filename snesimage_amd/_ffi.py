@@ -29,6 +29,7 @@ SIGNATURES = [
     ("snesimage_recalculate_palettes", C.c_int32, [C.c_void_p]),
     ("snesimage_optimize", C.c_int32, [C.c_void_p]),
     ("snesimage_error", C.c_int32, [C.c_void_p, _f64p]),
+    ("snesimage_reassign_tiles", C.c_int32, [C.c_void_p, _u32p]),
     ("snesimage_score_candidates", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, _u8p, C.c_uint32, _f64p]),
     ("snesimage_score_candidates_device", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
                                                       C.c_void_p, C.c_void_p]),

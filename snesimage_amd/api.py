@@ -118,6 +118,12 @@ class OptimizedImage:
         self._chk(self._L.snesimage_error(self._c, C.byref(out)))
         return out.value
 
+    def reassign_tiles(self):
+        """Move every tile to the subpalette that reproduces it best (not in the reference: TODO.md:36-37); tiles moved."""
+        moved = C.c_uint32(0)
+        self._chk(self._L.snesimage_reassign_tiles(self._c, C.byref(moved)))
+        return moved.value
+
     def score_candidates(self, palette, index, rgb5):
         """Loop body of lib.rs:205-220 for an explicit candidate list -> errors (float64)."""
         cand = np.ascontiguousarray(rgb5, np.uint8).reshape(-1, 3)

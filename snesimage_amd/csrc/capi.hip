@@ -1204,6 +1204,42 @@ int32_t snesimage_recalculate_palettes(snesimage_ctx *c) {
     return kmeans_recalculate_palettes(c);
 }
 
+// Not in the reference (TODO.md:36-37 names it as missing): move every tile to the subpalette that reproduces it best.
+int32_t snesimage_reassign_tiles(snesimage_ctx *c, uint32_t *moved_out) {
+    if (!c) return fail(SNES_ERR_ARG, "null context");
+    CHECK(set_device(c));
+    CHECK(ensure_map(c)); // an optimize() still owed belongs to the state before this change
+    CHECK(ensure_tables(c));
+    if (c->perceptual) CHECK(ensure_source(c));
+    const int ntile = (int)((c->W / 8) * (c->H / 8)), n = ntile * (int)c->sub_count;
+    double *d_cost = nullptr; int *d_any = nullptr; unsigned int *d_moved = nullptr;
+    auto cleanup = [&]() { if (d_cost) (void)hipFree(d_cost); if (d_any) (void)hipFree(d_any); if (d_moved) (void)hipFree(d_moved); };
+    unsigned int moved = 0;
+    auto body = [&]() -> int32_t {
+        HIPCHK(hipMalloc(&d_cost, sizeof(double) * n));
+        HIPCHK(hipMalloc(&d_any, sizeof(int) * ntile));
+        HIPCHK(hipMalloc(&d_moved, sizeof(unsigned int)));
+        HIPCHK(hipMemsetAsync(d_moved, 0, sizeof(unsigned int), c->stream));
+        hipLaunchKernelGGL(k_tile_costs, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_orig, c->d_pal_rgb8, c->d_pal_lab, c->d_labpx, (int)c->W, (int)c->H, (int)c->sub_count,
+                           (int)c->sub_size, c->perceptual ? 1 : 0, d_cost, d_any);
+        hipLaunchKernelGGL(k_tile_move, dim3((ntile + 255) / 256), dim3(256), 0, c->stream, d_cost, d_any, ntile, (int)c->sub_count, c->d_tile_pal, d_moved);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&moved, d_moved, sizeof(moved), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return SNES_OK;
+    };
+    const int32_t rc = body();
+    cleanup();
+    if (rc != SNES_OK) return rc;
+    if (moved) { // as after snesimage_set_tile_palettes, then optimize() (the palettes are kept)
+        c->pack_valid = false; c->inc_valid = false; c->map_synced = false;
+        CHECK(do_optimize(c));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    if (moved_out) *moved_out = moved;
+    return SNES_OK;
+}
+
 int32_t snesimage_timing_enable(snesimage_ctx *c, int32_t on) {
     if (!c) return fail(SNES_ERR_ARG, "null context");
     CHECK(set_device(c));

@@ -59,6 +59,8 @@ void usage() {
             "      --devices <A,B,..>   shard every call's candidates over these devices (RCCL inside the library)\n"
             "      --tile-palettes <F>  1024-byte tile->subpalette override\n      --resume <F>         start from the palette and tile palettes of a previous JSON output\n"
             "      --preview <F>        write source | result as a PNG\n"
+            "      --reassign-tiles <K> every K sweeps of the palette, move each tile to the subpalette that reproduces it best\n"
+            "                           (off by default; not in the reference: its TODO.md lists it as missing)\n"
             "      --decode-only        write the decoded source as raw RGBA8 to <TARGET_FILENAME> and stop (no GPU)\n  -h, --help\n  -V, --version\n");
 }
 // the flat integer array stored under `"key":[...]` in one of this driver's (or the reference's) JSON outputs
@@ -102,7 +104,7 @@ void synth(uint64_t seed, uint32_t w, uint32_t h, std::vector<uint8_t> &out) { /
 
 int main(int argc, char **argv) {
     std::vector<std::string> pos;
-    uint32_t count = 1, size = 7, flags = 0, calls = 0, ncand = 64; // src/config.rs:13-18 defaults
+    uint32_t count = 1, size = 7, flags = 0, calls = 0, ncand = 64, reassign_every = 0; // src/config.rs:13-18 defaults
     uint64_t seed = 1;
     int device = 0;
     std::string tile_file, preview_file, resume_file;
@@ -123,6 +125,7 @@ int main(int argc, char **argv) {
         else if (a == "--devices") { for (const char *q = need("--devices"); *q;) { char *end = nullptr; devices.push_back((int)strtol(q, &end, 10)); if (end == q) { fprintf(stderr, "error: invalid value for '--devices'\n"); return 2; } q = *end == ',' ? end + 1 : end; } }
         else if (a == "--tile-palettes") tile_file = need("--tile-palettes");
         else if (a == "--preview") preview_file = need("--preview");
+        else if (a == "--reassign-tiles") reassign_every = (uint32_t)strtoul(need("--reassign-tiles"), nullptr, 10);
         else if (a == "--resume") resume_file = need("--resume");
         else if (a == "--decode-only") decode_only = true;
         else if (a == "-h" || a == "--help") { usage(); return 0; }
@@ -214,7 +217,7 @@ int main(int argc, char **argv) {
         log_info("Sharding candidates over " + std::to_string(members.size()) + " device(s)");
     }
     log_info("Beginning optimization"); // src/lib.rs:992
-    uint32_t palette = 0, index = 0, channel = 0, step = 0;
+    uint32_t palette = 0, index = 0, channel = 0, step = 0, sweep = 0;
     double last_error = 1.7976931348623157e308;
     std::vector<uint8_t> before(3 * (size_t)count * size), after(before.size());
     for (uint32_t call = 0; call < calls; call++) {
@@ -232,6 +235,12 @@ int main(int argc, char **argv) {
             log_info(m);
         }
         if (std::abs(error - last_error) > 2.220446049250313e-16) { log_info("Current Error: " + fmt_f64(error)); last_error = error; } // src/lib.rs:912-915
+        if (reassign_every && step != sweep && step % reassign_every == 0) { // a sweep over every slot has just ended (src/lib.rs:925-931)
+            uint32_t moved = 0;
+            for (snesimage_ctx *m : members) if (snesimage_reassign_tiles(m, &moved) != 0) die(std::string("Unable to reassign tiles: ") + snesimage_last_error());
+            log_info("Reassigned " + std::to_string(moved) + " tiles");
+        }
+        sweep = step;
     }
     log_info("Writing output to " + target); // src/lib.rs:1000-1002
     int64_t need = snesimage_as_json(ctx, nullptr, 0);

@@ -589,6 +589,53 @@ __global__ void k_gather_points(const uint8_t *__restrict__ orig, const float *_
     else { uint32_t o = reinterpret_cast<const uint32_t *>(orig)[px]; pts[3 * i] = (double)(o & 0xff); pts[3 * i + 1] = (double)((o >> 8) & 0xff); pts[3 * i + 2] = (double)((o >> 16) & 0xff); }
 }
 
+// ---- dynamic tile -> subpalette reassignment (snesimage_reassign_tiles; not in the reference, TODO.md:36-37) ----------
+// cost[tile][p] = sum over the tile's opaque pixels, raster order inside the tile, of the distance optimize() minimises
+// (lib.rs:1080-1100) to the nearest entry of subpalette p, in binary64.  The redmean distance is sqrt(key / 512) with the
+// exact integer key of red_mean_key: bit-identical to the reference's expression, whose every intermediate is exact.
+// thread = (tile, subpalette): the sum is one ordered chain of at most 64 terms.
+__global__ void k_tile_costs(const uint8_t *__restrict__ orig, const uint32_t *__restrict__ pal_rgb8, const float *__restrict__ pal_lab, const float *__restrict__ labpx, int W, int H,
+                             int sub_count, int sub_size, int perceptual, double *__restrict__ cost, int *__restrict__ any) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int wt = W / 8, ntile = wt * (H / 8);
+    if (i >= ntile * sub_count) return;
+    const int tile = i / sub_count, p = i - tile * sub_count;
+    const int tx = tile % wt, ty = tile / wt;
+    double c = 0.0; int a = 0;
+    for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 8; x++) {
+            const size_t px = (size_t)(ty * 8 + y) * W + tx * 8 + x;
+            const uint32_t o = reinterpret_cast<const uint32_t *>(orig)[px];
+            if ((o >> 24) == 0) continue;
+            a = 1;
+            if (!perceptual) {
+                uint32_t bk = 0xffffffffu;
+                for (int j = 0; j < sub_size; j++) { const uint32_t k = red_mean_key(pal_rgb8[p * sub_size + j], o & 0x00ffffffu); if (k < bk) bk = k; }
+                c = c + sqrt((double)bk / 512.0);
+            } else {
+                Lab t; t.l = labpx[3 * px]; t.a = labpx[3 * px + 1]; t.b = labpx[3 * px + 2];
+                float bd = 0.0f;
+                for (int j = 0; j < sub_size; j++) {
+                    Lab e; e.l = pal_lab[3 * (p * sub_size + j)]; e.a = pal_lab[3 * (p * sub_size + j) + 1]; e.b = pal_lab[3 * (p * sub_size + j) + 2];
+                    const float d = ciede2000(e, t);
+                    if (j == 0 || d < bd) bd = d;
+                }
+                c = c + (double)bd;
+            }
+        }
+    cost[i] = c;
+    if (p == 0) any[tile] = a;
+}
+// the move: strictly smallest cost, scanning upwards from the current subpalette's (ties keep the current one, then the lower index)
+__global__ void k_tile_move(const double *__restrict__ cost, const int *__restrict__ any, int ntile, int sub_count, uint8_t *__restrict__ tile_pal, unsigned int *__restrict__ moved) {
+    const int tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= ntile || !any[tile]) return;
+    const int cur = tile_pal[tile];
+    int best = cur;
+    for (int p = 0; p < sub_count; p++) if (cost[tile * sub_count + p] < cost[tile * sub_count + best]) best = p;
+    if (best != cur) { tile_pal[tile] = (uint8_t)best; atomicAdd(moved, 1u); }
+}
+
 // ---- kernel entry points of the bodies above ----
 __global__ void k_gen_candidates(int method, int n, unsigned long long key, const uint8_t *__restrict__ colors, int slot, int channel, uint8_t *__restrict__ cand,
                                  int rank = 0, int count = 1, uint8_t *__restrict__ sel = nullptr, double *__restrict__ errors = nullptr) {

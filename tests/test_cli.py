@@ -82,6 +82,35 @@ def test_cli_end_to_end_matches_oracle(tmp_path, O, extra, count, size, flags):
     assert r2.returncode == 0 and out2.read_text() == text
 
 
+@pytest.mark.gpu
+def test_cli_reassign_tiles_matches_oracle(tmp_path, O):
+    """--reassign-tiles 1 (not in the reference: TODO.md:36-37): after every sweep over the slots (2 x 3 entries: calls 6, 12,
+    ...) each tile moves to the subpalette that reproduces it best; the JSON is the oracle's doing the same, and without
+    the flag the output is untouched by the feature."""
+    from snesimage_amd.synth import synth_image
+    seed_img, calls, ncand, count, size = 0x5EED0004, 14, 12, 2, 3
+    img = synth_image(seed_img)
+    out = tmp_path / "out.json"
+    r = run("synth:%d" % seed_img, str(out), "-c", str(count), "-s", str(size), "--calls", str(calls), "--candidates", str(ncand), "--seed", "5",
+            "--reassign-tiles", "1")
+    assert r.returncode == 0, r.stdout + r.stderr
+    o = O.OracleImage(img, count, size)
+    o.initialize_tiles()
+    o.recalculate_palettes()
+    moved = []
+    sched = O.schedule(count, size, calls + 1)
+    for i, (method, p, idx, ch, step) in enumerate(sched[:calls]):
+        o.step(method, p, idx, ch, 5, i, ncand if method == 0 else 0)
+        if sched[i + 1][4] != step:  # the sweep counter advanced
+            moved.append(o.reassign_tiles())
+    assert len(moved) == 2 and moved[0] > 0
+    assert [int(l.split("Reassigned ")[1].split()[0]) for l in r.stdout.splitlines() if "Reassigned " in l] == moved
+    assert out.read_text() == o.as_json()
+    plain = tmp_path / "plain.json"
+    r2 = run("synth:%d" % seed_img, str(plain), "-c", str(count), "-s", str(size), "--calls", str(calls), "--candidates", str(ncand), "--seed", "5")
+    assert r2.returncode == 0 and "Reassigned" not in r2.stdout and plain.read_text() != out.read_text()
+
+
 def read_plain_png(data):
     """Decoder for what the driver writes: RGBA8, filter 0 on every row."""
     import struct

@@ -591,6 +591,27 @@ def test_resumed_dither_equals_full_dither(S, O, seed, variant, monkeypatch):
     sparse.close()
 
 
+@pytest.mark.parametrize("flags", [{}, {"perceptual": True}, {"dither": True}])
+def test_reassign_tiles_matches_oracle(S, O, img256_alpha, flags):
+    """snesimage_reassign_tiles (not in the reference: TODO.md:36-37): tiles moved, tile_palettes, palette_map and error
+    against the oracle, straight after clustering and again after optimizer calls have changed the palette."""
+    g, o = pair(S, O, img256_alpha, 4, 7, **flags)
+    g.initialize_tiles(); o.initialize_tiles()
+    g.recalculate_palettes(); o.recalculate_palettes()
+    for rnd in range(2):
+        mg, mo = g.reassign_tiles(), o.reassign_tiles()
+        assert mg == mo and (rnd > 0 or mo > 0)
+        assert np.array_equal(g.tile_palettes, o.tile_palettes) and np.array_equal(g.palette_map, o.palette_map)
+        assert rel(g.error(), o.error()) < REL_ERR
+        assert g.reassign_tiles() == 0
+        for i, (p, idx) in enumerate([(0, 0), (3, 6), (1, 2)]):
+            eg, bg = g.step(S.METHOD_RANDOM, p, idx, 0, 3, 10 * rnd + i, 24)
+            eo, bo = o.step(0, p, idx, 0, 3, 10 * rnd + i, 24)
+            assert np.array_equal(bg, bo) and abs(eg - eo) <= REL_ERR * abs(eo)
+    assert g.as_json() == o.as_json()
+    g.close()
+
+
 # ---- one process, several devices: RCCL inside the library ---------------------------------------------
 def test_group_step_over_rccl_equals_plain_step(S, img256):
     """snesimage_group_* with the devices this box has (one): step_begin -> grouped ncclAllReduce(min) -> step_commit must

@@ -362,3 +362,47 @@ def test_oracle_matches_throughput_golden(O):
     assert hashlib.sha256(np.ascontiguousarray(o.palette_map).tobytes()).hexdigest() == rec["map_sha"]
     assert [float(e).hex() for e in errs] == rec["errors_hex"]
     assert hashlib.sha256(o.as_json().encode()).hexdigest() == rec["json_sha"]
+
+
+# ---- dynamic tile reassignment (not in the reference: TODO.md:36-37; definition in oracle/snes_oracle.cpp) ------------
+def test_reassign_tiles_semantics(O):
+    """A tile painted in a colour only subpalette 1 holds moves there; a tile both subpalettes reproduce equally stays;
+    transparent tiles never move; a second call moves nothing; the remap distance summed over the image never grows."""
+    img = np.zeros((256, 256, 4), np.uint8)
+    img[..., 3] = 255
+    img[..., :3] = (8, 8, 8)             # 5-bit (1,1,1) expands to exactly (8,8,8)
+    img[0:8, 8:16, :3] = (255, 0, 0)     # tile 1: pure red
+    img[8:16, 0:8, 3] = 0                # tile 32: transparent
+    o = O.OracleImage(img, 2, 3)
+    pal = np.zeros((6, 3), np.uint8)
+    pal[0] = (1, 1, 1); pal[1] = (0, 0, 0); pal[2] = (2, 2, 2)       # subpalette 0: greys
+    pal[3] = (31, 0, 0); pal[4] = (1, 1, 1); pal[5] = (0, 31, 0)     # subpalette 1: red, the same grey, green
+    o.palette = pal
+    tp = np.zeros(1024, np.uint8)
+    tp[32] = 1                            # the transparent tile sits in subpalette 1 and must stay there
+    tp[5] = 1                             # a grey tile in subpalette 1: cost 0 in both -> stays
+    o.tile_palettes = tp
+    o.optimize()
+    assert o.reassign_tiles() == 1
+    got = o.tile_palettes
+    assert got[1] == 1 and got[32] == 1 and got[5] == 1 and got[0] == 0 and got.sum() == 3
+    assert o.palette_map[0, 8] == 0 and o.palette_map[40, 40] == 0     # red -> entry 0 of subpalette 1; grey -> entry 0 of subpalette 0
+    assert o.reassign_tiles() == 0
+
+
+def test_reassign_tiles_lowers_the_remap_cost(O, img256):
+    def remap_cost(o):
+        pal8 = (o.palette.astype(np.int64) * 8 + o.palette.astype(np.int64) // 4).reshape(o.sub_count, o.sub_size, 3)
+        sub = np.asarray(o.tile_palettes).reshape(32, 32).repeat(8, 0).repeat(8, 1)
+        c = pal8[sub, o.palette_map].astype(np.float64)
+        t = img256[..., :3].astype(np.float64)
+        rm = (c[..., 0] + t[..., 0]) / 2
+        d = c - t
+        return float(np.sqrt((512 + rm) * d[..., 0] ** 2 / 256 + 4 * d[..., 1] ** 2 + (767 - rm) * d[..., 2] ** 2 / 256).sum())
+    o = O.OracleImage(img256, 8, 15)
+    o.initialize_tiles()
+    o.recalculate_palettes()
+    before = remap_cost(o)
+    assert o.reassign_tiles() > 0
+    assert remap_cost(o) < before
+    assert o.reassign_tiles() == 0
