@@ -134,7 +134,7 @@ def main():
                     help="candidates per optimizer call per GPU (weak) or in total (strong); default 4096, and the reference's 64 "
                          "(lib.rs:205) for --config images")
     ap.add_argument("--images", type=int, default=128, help="--config images: images per GPU (1,024 over 8 GPUs)")
-    ap.add_argument("--host-threads", type=int, default=8, help="--config images: host threads enqueueing optimizer calls")
+    ap.add_argument("--host-threads", type=int, default=16, help="--config images: host threads initialising images / enqueueing per-image calls")
     ap.add_argument("--perceptual", action="store_true", help="--config images: CIEDE2000 distance (--perceptual-palettes)")
     ap.add_argument("--groups", type=int, default=4, help="--config images: batches stepped side by side on their own streams")
     ap.add_argument("--per-image-launches", action="store_true",

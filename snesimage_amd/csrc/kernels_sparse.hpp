@@ -369,12 +369,12 @@ __device__ __forceinline__ void dither_diff_body(const SparseParams &P) {
 // ---- downscale chain + XYB on changed groups only -------------------------------------------------------
 // base: grid.x blocks share the rows of each scale (launched once per scale, P.ncand = scale to do);
 // candidates: one block per candidate walks the scales itself.
-__device__ __forceinline__ void sparse_down_body(const SparseParams &P, int only_scale) {
+__device__ __forceinline__ void sparse_down_body(const SparseParams &P, int only_scale, const int bx) { // bx: blockIdx.x unless the caller remaps blocks
     __shared__ float s_lin[256 * 3];
     const Geom &G = P.G;
     const int t = threadIdx.x;
     const bool is_base = P.is_base != 0;
-    const int k = is_base ? P.base : P.k0 + (int)blockIdx.x;
+    const int k = is_base ? P.base : P.k0 + bx;
     for (int i = t; i < (P.ncol + 2) * 3; i += 256) s_lin[i] = P.pal_lin[i];
     __syncthreads();
     if (t < 3 && !is_base) s_lin[3 * P.ncol + t] = P.cand_tab[8 * (size_t)k + t];
@@ -384,7 +384,7 @@ __device__ __forceinline__ void sparse_down_body(const SparseParams &P, int only
     float *mine = P.store + (size_t)k * P.S.cand_stride;
     const float *basep = P.store + (size_t)P.base * P.S.cand_stride;
     const int s_lo = only_scale > 0 ? only_scale : 1, s_hi = only_scale > 0 ? only_scale + 1 : G.nscales;
-    const int part0 = is_base ? (int)blockIdx.x : 0, nparts = is_base ? (int)gridDim.x : 1;
+    const int part0 = is_base ? bx : 0, nparts = is_base ? (int)gridDim.x : 1;
     for (int s = s_lo; s < s_hi; s++) {
         const int Ws = G.sw[s], Wp = G.sw[s - 1];
         const int n = M->ngroups[s];
@@ -967,7 +967,7 @@ __global__ __launch_bounds__(256) void k_sparse_scan_lab(SparseParams P) { spars
 __global__ __launch_bounds__(1024) void k_sparse_scan(SparseParams P) { sparse_scan_body(P); }
 __global__ __launch_bounds__(1024) void k_dither_first(SparseParams P) { dither_first_body(P); }
 __global__ __launch_bounds__(1024) void k_dither_diff(SparseParams P) { dither_diff_body(P); }
-__global__ __launch_bounds__(256) void k_sparse_down(SparseParams P, int only_scale) { sparse_down_body(P, only_scale); }
+__global__ __launch_bounds__(256) void k_sparse_down(SparseParams P, int only_scale) { sparse_down_body(P, only_scale, (int)blockIdx.x); }
 __global__ __launch_bounds__(256) void k_base_down(SparseParams P) { base_down_body(P); }
 __global__ __launch_bounds__(64) void k_sparse_h(SparseParams P) { sparse_h_body(P); }
 __global__ __launch_bounds__(256, 1) void k_sparse_v_base(SparseParams P) { sparse_v_base_body(P); }

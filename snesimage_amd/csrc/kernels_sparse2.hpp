@@ -47,8 +47,9 @@ namespace snes {
 // lane quad = the four rows of an item.  Column quads g run from 16*block to W/4; iteration g consumes the inputs of quad g
 // (the "right" taps in[n+4]) and yields the outputs of quad g-1; the five-slot register ring keeps quads g-3..g+1.
 // S0: scale 0 — the candidate's pixels come from the pack (win test) instead of an XYB plane.
+// bx / gx: the block's index and count among the blocks of its list (blockIdx.x / gridDim.x unless the caller remaps blocks)
 template <bool S0>
-__device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int list) {
+__device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int list, const int bx, const int gx) {
     constexpr int NP = S0 ? 4 : 3;        // staged planes: the three H outputs (+ the XYB input at scale 0)
     constexpr int ISTR = NP * 64 + 4;     // staging words per item; the pad spreads the quads' rows over the LDS banks
     __shared__ float s_lut[S0 ? 3 * 256 : 1];
@@ -59,7 +60,7 @@ __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int 
     const int W = G.sw[s], H = G.sh[s];
     const int lane = threadIdx.x;
     const int count = P.item_count[list];
-    if ((int)blockIdx.x * 16 >= count) return;
+    if (bx * 16 >= count) return;
     if (S0) {
         for (int i = lane; i < 3 * 256; i += 64) { const int c = i >> 8, j = i & 255; s_lut[i] = (j < P.ncol + 2) ? P.pal_xyb[3 * j + c] : 0.0f; }
         __syncthreads();
@@ -68,7 +69,7 @@ __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int 
     const float mp_0 = -P.K.d1[0], mp_1 = -P.K.d1[1], mp_2 = -P.K.d1[2];
     const int G4 = W >> 2, gs = cb << 4, gstart = gs >= 3 ? gs - 3 : 0; // three warm-up iterations refill the ring
     const int r = lane & 3;
-    for (int i0 = blockIdx.x * 16; i0 < count; i0 += gridDim.x * 16) { // grid-stride over item quads
+    for (int i0 = bx * 16; i0 < count; i0 += gx * 16) { // grid-stride over item quads
         const int qi = i0 + (lane >> 2);
         const bool valid = qi < count;
         const unsigned int it = P.items[(size_t)list * P.item_stride + (valid ? qi : i0)];
@@ -196,7 +197,7 @@ template <typename T> __device__ __forceinline__ T ld_at(const void *sbase, uint
 // BASE: the image B itself — every group is its own, the sweep starts at the top with a zero state and leaves the
 // checkpoint records behind (record g: state before group iteration g and pooling sums of rows < 4g-4; record H/4+1: final sums).
 template <bool BASE>
-__device__ __forceinline__ void sparse_v2_body(const SparseParams &P, const int s) {
+__device__ __forceinline__ void sparse_v2_body(const SparseParams &P, const int s, const int bx) { // bx: blockIdx.x unless the caller remaps blocks
     __shared__ short s_slot[4][64]; // per wave: group -> slot in the candidate's storage, -1 = B's group
     // tails: xy halves two deep, zw halves three deep, [slot][plane][thread]; the pooling reduction reuses the space
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[(2 + 3) * 3 * 256 * sizeof(float2)];
@@ -208,9 +209,9 @@ __device__ __forceinline__ void sparse_v2_body(const SparseParams &P, const int 
     const int wv = uni(t >> 6);
     const int wpp = W >> 6, ppw = 4 / wpp; // waves per pair, pairs per block
     const int npairs = BASE ? 3 : P.ncand * 3;
-    if ((int)blockIdx.x * ppw >= npairs) return;
+    if (bx * ppw >= npairs) return;
     const int ql = wv / wpp, xw = (wv - ql * wpp) << 6; // pair of the wave inside the block, first column of the wave
-    const int pair_raw = blockIdx.x * ppw + ql;
+    const int pair_raw = bx * ppw + ql;
     const bool active = pair_raw < npairs;
     const int pair = active ? pair_raw : 0;
     const int k = BASE ? P.base : uni(P.k0 + (P.order ? P.order[pair / 3] : pair / 3)), ch = pair % 3;
@@ -364,16 +365,16 @@ __device__ __forceinline__ void sparse_v2_body(const SparseParams &P, const int 
 #undef SNES_VSTEP
 
 // entry points: the H pass takes the lists of the wide scales (grid.y = list), the V pass the wide scales (grid.y = scale)
-__device__ __forceinline__ void sparse_h2_dispatch(const SparseParams &P) {
-    const int list = (int)blockIdx.y, s = list / kColBuckets;
+__device__ __forceinline__ void sparse_h2_dispatch(const SparseParams &P, const int list, const int bx, const int gx) {
+    const int s = list / kColBuckets;
     if (s >= P.G.nscales || P.G.sw[s] < 64 || (list % kColBuckets) >= (P.G.sw[s] >> 6)) return;
-    if (s == 0) sparse_h2_body<true>(P, list); else sparse_h2_body<false>(P, list);
+    if (s == 0) sparse_h2_body<true>(P, list, bx, gx); else sparse_h2_body<false>(P, list, bx, gx);
 }
-__global__ __launch_bounds__(64) void k_sparse_h2(SparseParams P) { sparse_h2_dispatch(P); }
-__global__ __launch_bounds__(256, 4) void k_sparse_v2(SparseParams P) { if ((int)blockIdx.y < P.G.nscales && P.G.sw[blockIdx.y] >= 64) sparse_v2_body<false>(P, (int)blockIdx.y); }
+__global__ __launch_bounds__(64) void k_sparse_h2(SparseParams P) { sparse_h2_dispatch(P, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x); }
+__global__ __launch_bounds__(256, 4) void k_sparse_v2(SparseParams P) { if ((int)blockIdx.y < P.G.nscales && P.G.sw[blockIdx.y] >= 64) sparse_v2_body<false>(P, (int)blockIdx.y, (int)blockIdx.x); }
 // B: the wide scales in this body (grid.y = scale), the narrow ones in the general one (grid.y = scale - s_first), two launches:
 // one kernel holding both bodies would take the larger register allocation for every block
-__global__ __launch_bounds__(256) void k_sparse_v2_base(SparseParams P) { if ((int)blockIdx.y < P.G.nscales && P.G.sw[blockIdx.y] >= 64) sparse_v2_body<true>(P, (int)blockIdx.y); }
+__global__ __launch_bounds__(256) void k_sparse_v2_base(SparseParams P) { if ((int)blockIdx.y < P.G.nscales && P.G.sw[blockIdx.y] >= 64) sparse_v2_body<true>(P, (int)blockIdx.y, (int)blockIdx.x); }
 __device__ __forceinline__ void sparse_v_base_narrow_dispatch(const SparseParams &P) { const int s = (int)blockIdx.y + P.s_first; if (s < P.G.nscales) sparse_v_body<false, 0, 1>(P, s); }
 __global__ __launch_bounds__(256, 1) void k_sparse_v_base_narrow(SparseParams P) { sparse_v_base_narrow_dispatch(P); }
 
