@@ -102,6 +102,18 @@ def bench_images(args, torch, dist, S, world, rank, local_rank, device, force_di
     if rank == 0:
         total = len(batch) * world * args.batch * args.steps  # (ranks hold equal blocks; an image dropped at initialisation is not counted)
         value = total / dt
+        # HBM bytes of one step (every batched kernel of one optimizer call on all images of this GPU) from the committed PMC
+        # passes of this mode, scaled by the candidates per step; null for variants without a committed measurement
+        traffic, traffic_src = None, None
+        try:
+            if not args.perceptual and not args.per_image_launches:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_images.json")))
+                per_call = sum(k["hbm_bytes_corrected_per_dispatch"] * k["FETCH_SIZE"]["dispatches"] for n, k in pmc["kernels"].items()
+                               if "::kb_" in n and "hbm_bytes_corrected_per_dispatch" in k) / float(pmc["calls"])
+                traffic = per_call * (len(batch) * args.batch) / float(pmc["candidates_per_call"])
+                traffic_src = "profiles/r2_pmc_images.json (all batched kernels of one call, %d candidates per call, scaled)" % pmc["candidates_per_call"]
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
+            traffic = None
         out = {
             "metric": "candidate palettes scored/sec", "value": value, "unit": "candidates/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -115,7 +127,7 @@ def bench_images(args, torch, dist, S, world, rank, local_rank, device, force_di
                        "mean_final_error": sum(errs) / len(errs)},
             "roofline": {"bound": "hbm", "kernel": "pipeline (kernels of different images overlap; no per-kernel timing in this mode)",
                          "achieved": value / world * ALGO_BYTES_PER_CANDIDATE / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": value / world * ALGO_BYTES_PER_CANDIDATE / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "frac": value / world * ALGO_BYTES_PER_CANDIDATE / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_candidate": ALGO_BYTES_PER_CANDIDATE},
         }
         print(json.dumps(out), flush=True)
@@ -294,7 +306,7 @@ def main():
         total = n_total * args.steps
         value = total / dt
         # dominant kernel of the launch group
-        sparse = (args.config in ("rgb", "perceptual") and os.environ.get("SNES_SPARSE", "1") != "0"
+        sparse = (os.environ.get("SNES_SPARSE", "1") != "0"  # (all three configurations take the group-sparse path)
                   and n_total // world >= int(os.environ.get("SNES_SPARSE_MIN", "64")))
         vname, hname = ("k_sparse_v2", "k_sparse_h2+k_sparse_h") if sparse else ("k_vpass_fast<scale0>", "k_hpass_fast<scale0>")
         dom = vname if tim["vpass0_ms"] >= tim["hpass0_ms"] else hname
