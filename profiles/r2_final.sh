@@ -3,22 +3,22 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/r2final; mkdir -p $O
-bash profiles/r2_pmc.sh r2final/pmc_rgb 2 2048 > $O/pmc_rgb.log 2>&1
-bash profiles/r2_pmc.sh r2final/pmc_perceptual 2 2048 --config perceptual > $O/pmc_perceptual.log 2>&1
-bash profiles/r2_pmc.sh r2final/pmc_dither 2 2048 --config dither > $O/pmc_dither.log 2>&1
+bash profiles/r2_pmc.sh r2final/pmc_rgb default 4096 > $O/pmc_rgb.log 2>&1
+bash profiles/r2_pmc.sh r2final/pmc_perceptual default 4096 --config perceptual > $O/pmc_perceptual.log 2>&1
+bash profiles/r2_pmc.sh r2final/pmc_dither default 2048 --config dither > $O/pmc_dither.log 2>&1
 bash profiles/r2_pmc.sh r2final/pmc_images 1 2048 --config images > $O/pmc_images.log 2>&1
 echo pmc done
 stats() { # name, lanes, bench args
   n=$1; l=$2; shift 2
-  ( cd /tmp && SNES_LANES=$l rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/kt_$n -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 25 --warmup 5 --no-cpu-baseline --no-extras "$@" > $GRAFT_REPO_ROOT/$O/kt_$n.log 2>&1 )
+  ( cd /tmp && [ "$l" != default ] && export SNES_LANES=$l; cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/kt_$n -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 25 --warmup 5 --no-cpu-baseline --no-extras "$@" > $GRAFT_REPO_ROOT/$O/kt_$n.log 2>&1 )
   f=$(find $O/kt_$n -name '*.db' | head -1); python profiles/dbstats.py $f 30 > $O/kernel_stats_$n.txt
 }
+stats rgb default
 stats rgb_lanes2 2
-stats rgb_lanes1 1
-stats rgb_batch64 2 --batch 64 --steps 200
-stats perceptual 2 --config perceptual
-stats dither 2 --config dither --steps 10 --warmup 2
-stats images 1 --config images --steps 20 --warmup 3
+stats rgb_batch64 default --batch 64 --steps 200
+stats perceptual default --config perceptual
+stats dither default --config dither --steps 10 --warmup 2
+stats images default --config images --steps 20 --warmup 3
 echo stats done
 python bench.py > $O/bench_rgb.json 2> $O/bench_rgb.err
 python bench.py --config perceptual --steps 100 > $O/bench_perceptual.json 2> $O/bench_perceptual.err

@@ -8,7 +8,7 @@ O=gpurun_out/$1; L=$2; CPL=$3; shift 3
 mkdir -p $O
 run() { # name, counters...
   n=$1; shift
-  ( cd /tmp && SNES_LANES=$L rocprofv3 --kernel-trace --pmc "$@" -d $GRAFT_REPO_ROOT/$O/$n -o p -f csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras $BENCH_ARGS > $GRAFT_REPO_ROOT/$O/$n.log 2>&1 )
+  ( cd /tmp && [ "$L" != default ] && export SNES_LANES=$L; cd /tmp && rocprofv3 --kernel-trace --pmc "$@" -d $GRAFT_REPO_ROOT/$O/$n -o p -f csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras $BENCH_ARGS > $GRAFT_REPO_ROOT/$O/$n.log 2>&1 )
 }
 BENCH_ARGS="$*"
 run fetch FETCH_SIZE

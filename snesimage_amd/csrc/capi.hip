@@ -783,6 +783,11 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     c->npx = (size_t)w * h;
     c->K = make_blur_constants();
     if (const char *e = getenv("SNES_CHUNK")) { int v = atoi(e); if (v > 0) c->chunk = (uint32_t)v; }
+    // Launch lanes: a candidate list is split evenly over them.  Without dither the stages of a launch group saturate the
+    // chip one after the other (V pass: VALU, H pass: its writes) and a second lane in lock-step only shares it (+3 % at
+    // 4,096 per call, and every kernel's duration doubles): one lane.  With --dither the resumed Floyd-Steinberg runs
+    // (latency-bound wavefronts) overlap the other lane's scoring: two (+10 %).
+    c->nlanes = c->dither ? 2u : 1u;
     if (const char *e = getenv("SNES_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->nlanes = (uint32_t)v; }
     // the group-sparse path covers, at the full size, the no-dither remap (RGB keys or CIEDE2000) and the RGB Floyd-Steinberg remap
     c->sp.enabled = (h == 256) && !(c->dither && c->perceptual);
