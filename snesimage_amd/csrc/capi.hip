@@ -594,8 +594,12 @@ struct LaneScope {
 
 // errors of candidate j of the list go to d_errors[err_offset + j * err_stride]
 int32_t score_list(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t n, double *d_errors, int err_stride, int err_offset, int sp, int si, uint8_t *d_maps_out) {
-    // one launch group per lane when the list allows it (fewer, larger launches; the V pass sorts each group by length)
-    uint32_t chunk = (n + c->nlanes - 1) / c->nlanes;
+    // Launch groups of at most `chunk` candidates, dealt to the launch lanes.  Without dither the stages of a launch group
+    // saturate the chip one after the other (V pass: VALU, H pass: its writes): splitting a list that fits one group over two
+    // lanes in lock-step only makes them share it (+3 % at 4,096 per call, every kernel's duration doubled), so such a list is
+    // one group on one lane; longer lists alternate between the lanes (+8 % at 8,192).  With --dither the resumed
+    // Floyd-Steinberg runs (latency-bound wavefronts) overlap the other lane's scoring: the list is split evenly (+10 %).
+    uint32_t chunk = c->dither ? (n + c->nlanes - 1) / c->nlanes : n;
     if (chunk < 64) chunk = 64;
     if (chunk > c->chunk) chunk = c->chunk;
     const bool sparse = c->sp.enabled && !d_maps_out && sp >= 0 && n >= c->sp.min_n && c->pack_mode == (c->dither ? 1 : 2);
@@ -783,11 +787,6 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     c->npx = (size_t)w * h;
     c->K = make_blur_constants();
     if (const char *e = getenv("SNES_CHUNK")) { int v = atoi(e); if (v > 0) c->chunk = (uint32_t)v; }
-    // Launch lanes: a candidate list is split evenly over them.  Without dither the stages of a launch group saturate the
-    // chip one after the other (V pass: VALU, H pass: its writes) and a second lane in lock-step only shares it (+3 % at
-    // 4,096 per call, and every kernel's duration doubles): one lane.  With --dither the resumed Floyd-Steinberg runs
-    // (latency-bound wavefronts) overlap the other lane's scoring: two (+10 %).
-    c->nlanes = c->dither ? 2u : 1u;
     if (const char *e = getenv("SNES_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->nlanes = (uint32_t)v; }
     // the group-sparse path covers, at the full size, the no-dither remap (RGB keys or CIEDE2000) and the RGB Floyd-Steinberg remap
     c->sp.enabled = (h == 256) && !(c->dither && c->perceptual);
