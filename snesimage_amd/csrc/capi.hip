@@ -594,12 +594,13 @@ struct LaneScope {
 
 // errors of candidate j of the list go to d_errors[err_offset + j * err_stride]
 int32_t score_list(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t n, double *d_errors, int err_stride, int err_offset, int sp, int si, uint8_t *d_maps_out) {
-    // Launch groups of at most `chunk` candidates, dealt to the launch lanes.  Without dither the stages of a launch group
-    // saturate the chip one after the other (V pass: VALU, H pass: its writes): splitting a list that fits one group over two
-    // lanes in lock-step only makes them share it (+3 % at 4,096 per call, every kernel's duration doubled), so such a list is
-    // one group on one lane; longer lists alternate between the lanes (+8 % at 8,192).  With --dither the resumed
-    // Floyd-Steinberg runs (latency-bound wavefronts) overlap the other lane's scoring: the list is split evenly (+10 %).
-    uint32_t chunk = c->dither ? (n + c->nlanes - 1) / c->nlanes : n;
+    // Launch groups of at most `chunk` candidates, dealt to the launch lanes.  With the RGB distance and no dither the stages
+    // of a launch group saturate the chip one after the other (V pass: VALU, H pass: its writes): splitting a list that fits
+    // one group over two lanes in lock-step only makes them share it (+3 % at 4,096 per call, every kernel's duration
+    // doubled), so such a list is one group on one lane; longer lists alternate between the lanes.  The CIEDE2000 scan and the
+    // resumed Floyd-Steinberg runs are latency-bound and do overlap the other lane's scoring: those lists are split evenly
+    // (+7 % with --perceptual-palettes, +10 % with --dither).
+    uint32_t chunk = (c->dither || c->perceptual) ? (n + c->nlanes - 1) / c->nlanes : n;
     if (chunk < 64) chunk = 64;
     if (chunk > c->chunk) chunk = c->chunk;
     const bool sparse = c->sp.enabled && !d_maps_out && sp >= 0 && n >= c->sp.min_n && c->pack_mode == (c->dither ? 1 : 2);

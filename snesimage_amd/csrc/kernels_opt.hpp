@@ -96,13 +96,17 @@ __device__ __forceinline__ uint32_t dither_group_min(const uint4 *__restrict__ e
 // MODE 2: a candidate, resumed: Floyd-Steinberg is causal in raster order, so up to its first won pixel the candidate's
 //         run IS B's run.  Rows above the 4-row group of that pixel are copied from B's map, the state entering the group
 //         comes from B's checkpoint, and only the rows from there on are dithered (all of them: the error spreads).
-template <bool PERC, int SUB, int MODE = 0>
-__global__ __launch_bounds__(128) void k_dither(DitherParams P) {
+// NT: threads per block = rows in flight.  A thread that finishes a row goes on with row y + NT, whose upper neighbour is the
+//     block's last thread, 2 (NT - 1) steps behind: its ring still holds the columns needed only if 2 (NT - 1) >= W - 2, i.e.
+//     NT = 128 at W = 256 (a 64-thread variant is not merely slower, it is wrong).
+template <bool PERC, int SUB, int MODE = 0, int NT = 128>
+__global__ __launch_bounds__(NT) void k_dither(DitherParams P) {
+    static_assert(2 * (NT - 1) >= 256 - 2, "the wavefront's ring is four columns deep: see NT above");
     __shared__ uint4 s_ent[256];
     __shared__ double s_ck[MODE == 2 ? 256 * 3 : 1]; // MODE 2: B's state entering the first row
     __shared__ float s_lab[PERC ? 256 * 3 : 1];
     __shared__ float s_eotf[PERC ? 256 : 1];
-    __shared__ double ring[128][4][3];
+    __shared__ double ring[NT][4][3];
     __shared__ uint8_t s_tile[1024];
     if (P.skip && *P.skip) return;
     const int j = threadIdx.x;
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(128) void k_dither(DitherParams P) {
     constexpr int W = 256; // snesimage_create admits no other width; a constant keeps the per-step index arithmetic to shifts
     const int H = P.H;
     const int sub_size = SUB ? SUB : P.sub_size;
-    for (int i = j; i < P.ncol; i += 128) {
+    for (int i = j; i < P.ncol; i += NT) {
         uint32_t c = P.pal_rgb8[i];
         if ((uint32_t)i == P.slot_ci) c = __float_as_uint(P.cand_tab[8 * (size_t)cand + 6]);
         const uint32_t r = c & 0xff, g = (c >> 8) & 0xff, b = (c >> 16) & 0xff;
@@ -120,8 +124,8 @@ __global__ __launch_bounds__(128) void k_dither(DitherParams P) {
             s_lab[3 * i] = src[0]; s_lab[3 * i + 1] = src[1]; s_lab[3 * i + 2] = src[2];
         }
     }
-    if (PERC) for (int i = j; i < 256; i += 128) s_eotf[i] = P.lab_eotf[i];
-    for (int i = j; i < 1024; i += 128) s_tile[i] = P.tile_pal[i];
+    if (PERC) for (int i = j; i < 256; i += NT) s_eotf[i] = P.lab_eotf[i];
+    for (int i = j; i < 1024; i += NT) s_tile[i] = P.tile_pal[i];
     for (int q = 0; q < 4; q++) { ring[j][q][0] = 0.0; ring[j][q][1] = 0.0; ring[j][q][2] = 0.0; }
     __syncthreads();
     const double w0 = 7.0 / 16.0, w1 = 3.0 / 16.0, w2 = 5.0 / 16.0, w3 = 1.0 / 16.0, mult = 0.8;
@@ -134,25 +138,25 @@ __global__ __launch_bounds__(128) void k_dither(DitherParams P) {
         y0 = min(4 * g0, H);
         // rows above are B's
         const uint32_t *b4 = reinterpret_cast<const uint32_t *>(P.bmap), *bC4 = reinterpret_cast<const uint32_t *>(P.bmapC4);
-        for (int i = j; i < y0 * (W >> 2); i += 128) map4[i] = b4[i];
-        if (mapC4) for (int i = j; i < y0 * (W >> 2); i += 128) { const int q = i / y0, yy = i - q * y0; mapC4[q * H + yy] = bC4[q * H + yy]; }
+        for (int i = j; i < y0 * (W >> 2); i += NT) map4[i] = b4[i];
+        if (mapC4) for (int i = j; i < y0 * (W >> 2); i += NT) { const int q = i / y0, yy = i - q * y0; mapC4[q * H + yy] = bC4[q * H + yy]; }
         if (y0 >= H) return;
-        if (y0 > 0) for (int i = j; i < W * 3; i += 128) s_ck[i] = P.ck_in[(size_t)g0 * W * 3 + i];
+        if (y0 > 0) for (int i = j; i < W * 3; i += NT) s_ck[i] = P.ck_in[(size_t)g0 * W * 3 + i];
         __syncthreads();
     }
     const int nrows = H - y0;
-    const int rows_per_thread = (nrows + 127) / 128; // 1 or 2 (H <= 256)
-    const int nth = nrows < 128 ? nrows : 128;
+    const int rows_per_thread = (nrows + NT - 1) / NT; // at most H / NT
+    const int nth = nrows < NT ? nrows : NT;
     const int total_steps = 2 * (nth - 1) + rows_per_thread * W;
     double left[3] = {0.0, 0.0, 0.0}; // v(x-1, y) of this thread's current row
     uint32_t macc = 0; // the four map bytes of the current x quad: one word store instead of scattered byte stores
-    const int up = (j + 127) & 127; // thread owning row y-1
+    const int up = (j + NT - 1) & (NT - 1); // thread owning row y-1
     // the source pixels of the NEXT x quad are fetched while the current quad is processed (the step is a dependent chain)
     const uint4 *orig4 = reinterpret_cast<const uint4 *>(P.orig);
     uint4 o_cur = make_uint4(0, 0, 0, 0), o_nxt = (y0 + j < H) ? orig4[(size_t)(y0 + j) * (W >> 2)] : make_uint4(0, 0, 0, 0);
     for (int t = 0; t < total_steps; t++) {
         const int local = t - 2 * j; // position in this thread's 512-pixel stream
-        const int x = local & (W - 1), y = y0 + j + 128 * (local >> 8);
+        const int x = local & (W - 1), y = y0 + j + NT * (local >> 8);
         const bool act = local >= 0 && local < rows_per_thread * W && y < H;
         if (act) {
             // every operand is fetched unconditionally and the border cases are selects, so the step has no divergent
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(128) void k_dither(DitherParams P) {
             if ((x & 3) == 0) { // this thread's stream continues with (x+4, y), then row y+128
                 o_cur = o_nxt;
                 const int ln = local + 4;
-                const int xn = ln & (W - 1), yn = y0 + j + 128 * (ln >> 8);
+                const int xn = ln & (W - 1), yn = y0 + j + NT * (ln >> 8);
                 if (ln < rows_per_thread * W && yn < H) o_nxt = orig4[((size_t)yn * W + xn) >> 2];
             }
             const uint32_t o = (x & 2) ? ((x & 1) ? o_cur.w : o_cur.z) : ((x & 1) ? o_cur.y : o_cur.x);
