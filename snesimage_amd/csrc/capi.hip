@@ -603,7 +603,9 @@ int32_t score_list(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t n, double *
     uint32_t chunk = (c->dither || c->perceptual) ? (n + c->nlanes - 1) / c->nlanes : n;
     if (chunk < 64) chunk = 64;
     if (chunk > c->chunk) chunk = c->chunk;
-    const bool sparse = c->sp.enabled && !d_maps_out && sp >= 0 && n >= c->sp.min_n && c->pack_mode == (c->dither ? 1 : 2);
+    // (--dither with one-entry subpalettes stays on the dense path: B then has no other entry to stand in for the slot's, so
+    // the slot's index appears in B's map as well and a map comparison cannot tell the candidate's pixels from B's)
+    const bool sparse = c->sp.enabled && !d_maps_out && sp >= 0 && n >= c->sp.min_n && c->pack_mode == (c->dither ? 1 : 2) && !(c->dither && c->sub_size == 1);
     CHECK(alloc_workspace(c, sparse ? 1 : chunk));
     CHECK(ensure_tables(c));
     CHECK(ensure_source(c));

@@ -612,6 +612,38 @@ def test_reassign_tiles_matches_oracle(S, O, img256_alpha, flags):
     g.close()
 
 
+@pytest.mark.parametrize("count,size", [(4, 1), (2, 2), (1, 15)])
+def test_resumed_dither_small_subpalettes(S, O, img256_alpha, count, size, monkeypatch):
+    """The resumed --dither path where B has no or a single other entry to fall back on (a one-entry subpalette: the candidate
+    takes every opaque pixel of the subpalette, from the first one), and with one subpalette for the whole image."""
+    monkeypatch.setenv("SNES_SPARSE", "0")
+    dense = S.OptimizedImage(img256_alpha, count, size, dither=True)
+    monkeypatch.delenv("SNES_SPARSE")
+    sparse = S.OptimizedImage(img256_alpha, count, size, dither=True)
+    rng = np.random.default_rng(5)
+    pal = rng.integers(0, 32, size=(count * size, 3)).astype(np.uint8)
+    tp = rng.integers(0, count, size=1024).astype(np.uint8)
+    for g in (dense, sparse):
+        g.tile_palettes = tp
+        g.palette = pal
+        g.optimize()
+    o = O.OracleImage(img256_alpha, count, size, dither=True)
+    o.tile_palettes = tp
+    o.palette = pal
+    o.optimize()
+    slot = (count - 1, size - 1)
+    cand = S.random_candidates(3, 1, 80)
+    cand[0] = pal[slot[0] * size + slot[1]]
+    ed, es = dense.score_candidates(slot[0], slot[1], cand), sparse.score_candidates(slot[0], slot[1], cand)
+    assert np.array_equal(ed, es)
+    assert rel(es[:4], o.score_candidates(slot[0], slot[1], cand[:4])) < REL_ERR
+    e_d, b_d = dense.step(S.METHOD_RANDOM, slot[0], slot[1], 0, 4, 0, 96)
+    e_s, b_s = sparse.step(S.METHOD_RANDOM, slot[0], slot[1], 0, 4, 0, 96)
+    assert e_d == e_s and np.array_equal(b_d, b_s) and np.array_equal(dense.palette_map, sparse.palette_map)
+    dense.close()
+    sparse.close()
+
+
 # ---- one process, several devices: RCCL inside the library ---------------------------------------------
 def test_group_step_over_rccl_equals_plain_step(S, img256):
     """snesimage_group_* with the devices this box has (one): step_begin -> grouped ncclAllReduce(min) -> step_commit must
