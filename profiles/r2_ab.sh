@@ -1,9 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r2v; mkdir -p $O
-for i in 1 2; do python bench.py --steps 150 --no-cpu-baseline > $O/rgb$i.json 2> $O/rgb$i.err; python -c "
+for q in 4 8 16; do for cfg in rgb perceptual dither; do st=100; [ $cfg = dither ] && st=30
+GPU_MAX_HW_QUEUES=$q python bench.py --config $cfg --steps $st --no-cpu-baseline > $O/q_${cfg}_$q.json 2> $O/q_${cfg}_$q.err; python -c "
 import json
-d=json.loads(open('$O/rgb$i.json').read().strip().splitlines()[-1]); print('rgb', round(d['value']), '%.3f' % d['ms_per_step'], 'ref64', round(d['reference_batch']['value']), d['roofline']['avg_launch_ms'], d['roofline']['group_ms'])"; done
-SNES_BASE_STREAM=0 python bench.py --steps 150 --no-cpu-baseline > $O/rgb3.json 2> $O/rgb3.err; python -c "
-import json
-d=json.loads(open('$O/rgb3.json').read().strip().splitlines()[-1]); print('rgb nobase', round(d['value']), '%.3f' % d['ms_per_step'], 'ref64', round(d['reference_batch']['value']))"
+d=json.loads(open('$O/q_${cfg}_$q.json').read().strip().splitlines()[-1]); print('$cfg queues $q', round(d['value']), '%.3f' % d['ms_per_step'], 'ref64', round(d['reference_batch']['value']))"; done; done
