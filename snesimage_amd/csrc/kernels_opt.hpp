@@ -103,7 +103,6 @@ template <bool PERC, int SUB, int MODE = 0, int NT = 128>
 __global__ __launch_bounds__(NT) void k_dither(DitherParams P) {
     static_assert(2 * (NT - 1) >= 256 - 2, "the wavefront's ring is four columns deep: see NT above");
     __shared__ uint4 s_ent[256];
-    __shared__ double s_ck[MODE == 2 ? 256 * 3 : 1]; // MODE 2: B's state entering the first row
     __shared__ float s_lab[PERC ? 256 * 3 : 1];
     __shared__ float s_eotf[PERC ? 256 : 1];
     __shared__ double ring[NT][4][3];
@@ -141,9 +140,14 @@ __global__ __launch_bounds__(NT) void k_dither(DitherParams P) {
         for (int i = j; i < y0 * (W >> 2); i += NT) map4[i] = b4[i];
         if (mapC4) for (int i = j; i < y0 * (W >> 2); i += NT) { const int q = i / y0, yy = i - q * y0; mapC4[q * H + yy] = bC4[q * H + yy]; }
         if (y0 >= H) return;
-        if (y0 > 0) for (int i = j; i < W * 3; i += NT) s_ck[i] = P.ck_in[(size_t)g0 * W * 3 + i];
-        __syncthreads();
     }
+    // MODE 2: the row above the first row is B's: its state (the checkpoint of the group) reaches thread 0 through a
+    // three-column register window refilled one step ahead — 6 KB of LDS less per block than staging the row, i.e. half as
+    // many blocks again per CU for a kernel that lives on occupancy
+    const bool ck_row = MODE == 2 && j == 0 && y0 > 0;
+    const double *ckp = MODE == 2 ? P.ck_in + (size_t)(y0 >> 2) * W * 3 : nullptr;
+    double ckw[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}}; // columns x-1, x, x+1
+    if (ck_row) { for (int c = 0; c < 3; c++) { ckw[1][c] = ckp[c]; ckw[2][c] = ckp[3 + c]; } }
     const int nrows = H - y0;
     const int rows_per_thread = (nrows + NT - 1) / NT; // at most H / NT
     const int nth = nrows < NT ? nrows : NT;
@@ -162,11 +166,15 @@ __global__ __launch_bounds__(NT) void k_dither(DitherParams P) {
             // every operand is fetched unconditionally and the border cases are selects, so the step has no divergent
             // branches and its LDS reads are all in flight together
             const double *ru0 = ring[up][(x - 1) & 3], *ru1 = ring[up][x & 3], *ru2 = ring[up][(x + 1) & 3];
-            if (MODE == 2 && y == y0) { ru0 = s_ck + 3 * ((x - 1) & (W - 1)); ru1 = s_ck + 3 * x; ru2 = s_ck + 3 * ((x + 1) & (W - 1)); } // the row above is B's
             const int base = (int)s_tile[(x >> 3) + (y >> 3) * (W >> 3)] * sub_size;
             double r0[3], r1[3], r2[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) { r0[c] = ru0[c]; r1[c] = ru1[c]; r2[c] = ru2[c]; }
+            if (MODE == 2 && ck_row && y == y0) { // the row above is B's
+#pragma unroll
+                for (int c = 0; c < 3; c++) { r0[c] = ckw[0][c]; r1[c] = ckw[1][c]; r2[c] = ckw[2][c]; ckw[0][c] = ckw[1][c]; ckw[1][c] = ckw[2][c]; }
+                if (x + 2 < W) { for (int c = 0; c < 3; c++) ckw[2][c] = ckp[3 * (x + 2) + c]; }
+            }
             if ((x & 3) == 0) { // this thread's stream continues with (x+4, y), then row y+128
                 o_cur = o_nxt;
                 const int ln = local + 4;
