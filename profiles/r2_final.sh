@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/r2final; mkdir -p $O
 bash profiles/r2_pmc.sh r2final/pmc_rgb default 4096 > $O/pmc_rgb.log 2>&1
-bash profiles/r2_pmc.sh r2final/pmc_perceptual default 4096 --config perceptual > $O/pmc_perceptual.log 2>&1
+bash profiles/r2_pmc.sh r2final/pmc_perceptual default 2048 --config perceptual > $O/pmc_perceptual.log 2>&1
 bash profiles/r2_pmc.sh r2final/pmc_dither default 2048 --config dither > $O/pmc_dither.log 2>&1
 bash profiles/r2_pmc.sh r2final/pmc_images 1 2048 --config images > $O/pmc_images.log 2>&1
 echo pmc done
