@@ -194,6 +194,29 @@ def test_chunking_does_not_change_results(S, O, img256):
     g.close()
 
 
+@pytest.mark.parametrize("flags", [{}, {"perceptual": True}, {"dither": True}])
+def test_launch_groups_and_lanes_do_not_change_results(S, img256_alpha, flags):
+    """A list longer than a launch group runs as several groups dealt to the lanes (and, with --dither, every lane keeps the
+    map of its best candidate across its groups): errors, the committed colour and the committed palette_map must not depend
+    on the group size.  400 candidates on the group-sparse path with groups of 4096, 150 and 64."""
+    ref = None
+    for chunk in (4096, 150, 64):
+        g = S.OptimizedImage(img256_alpha, 8, 15, **flags)
+        g.initialize_tiles()
+        g.recalculate_palettes()
+        g.set_chunk(chunk)
+        cand = S.random_candidates(21, 3, 400)
+        errs = g.score_candidates(5, 2, cand)
+        e, best = g.step(S.METHOD_RANDOM, 5, 2, 0, 21, 3, 400)
+        got = (errs, e, best, g.palette_map.copy(), g.error())
+        assert got[1] == min(got[0].min(), got[1]) and got[4] == got[1]
+        if ref is None:
+            ref = got
+        else:
+            assert np.array_equal(got[0], ref[0]) and got[1] == ref[1] and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3])
+        g.close()
+
+
 @pytest.mark.parametrize("h,count,size", [(8, 1, 3), (16, 2, 3), (32, 2, 7), (64, 4, 7), (128, 8, 15)])
 def test_small_heights(S, O, h, count, size):
     from snesimage_amd.synth import synth_image
