@@ -142,7 +142,7 @@ struct snesimage_ctx {
         uint32_t hgrid = 2048; // most blocks per scale of k_sparse_h (grid-stride beyond)
         bool enabled = false, side = true; uint32_t min_n = 64; uint32_t cap = 0; // cap = candidates per lane the arrays were sized for
         SparseGeom S{};
-        float *store = nullptr, *cand_tab = nullptr, *cand_lab = nullptr, *ckf = nullptr, *ckh = nullptr; uint32_t *bitmap = nullptr; double *cka = nullptr, *part = nullptr;
+        float *store = nullptr, *cand_tab = nullptr, *cand_lab = nullptr, *ckf = nullptr, *ckh = nullptr; long long zeros_off = 0; uint32_t *bitmap = nullptr; double *cka = nullptr, *part = nullptr;
         CandMeta *meta = nullptr; unsigned int *items = nullptr; int *item_count = nullptr; long long item_stride = 0; int *order = nullptr, *first = nullptr;
         uint4 *plist = nullptr; int *plist_count = nullptr; bool plist_valid = false;
         hipStream_t base_stream = nullptr; hipEvent_t ev_base_in = nullptr, ev_base_done = nullptr; // B's H and V passes run beside the candidates' scan/down/H
@@ -439,7 +439,10 @@ int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
         HIPCHK(dmalloc(&sp.bitmap, sizeof(uint32_t) * (c->npx / 32) * ncap));
     }
     HIPCHK(dmalloc(&sp.ckf, sizeof(float) * (size_t)okf));
-    dfree(sp.ckh); HIPCHK(dmalloc(&sp.ckh, sizeof(float) * (size_t)(okh ? okh : 1)));
+    // B's H-pass checkpoints, then 12 W floats of zeros (what the V pass prefetches for the group below the image)
+    dfree(sp.ckh); HIPCHK(dmalloc(&sp.ckh, sizeof(float) * (size_t)(okh + 12LL * G.W)));
+    sp.zeros_off = okh;
+    HIPCHK(hipMemsetAsync(sp.ckh + okh, 0, sizeof(float) * 12 * (size_t)G.W, c->stream));
     HIPCHK(dmalloc(&sp.cka, sizeof(double) * (size_t)oka));
     HIPCHK(dmalloc(&sp.part, sizeof(double) * ncap * kMaxScales * 18));
     HIPCHK(dmalloc(&sp.meta, sizeof(CandMeta) * ncap));
@@ -466,6 +469,7 @@ int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
         HIPCHK(dmalloc(&sp.dpack, sizeof(unsigned long long) * c->npx));
         HIPCHK(dmalloc(&sp.ckd, sizeof(double) * 3 * c->W * (c->H / 4 + 1)));
     }
+    HIPCHK(hipStreamSynchronize(c->stream)); // the clears above precede whatever the lanes and B's stream launch next
     sp.cap = need; sp.plist_valid = false;
     return SNES_OK;
 }
@@ -480,7 +484,7 @@ SparseParams sparse_params(snesimage_ctx *c, uint32_t lane) {
     P.img1C4 = c->d_img1C4; P.mu1R4 = c->d_mu1R4; P.sd1R4 = c->d_sd1R4; P.a1R4 = c->d_a1R4; P.r1R4 = c->d_r1R4;
     P.store = sp.store; P.meta = sp.meta;
     P.items = sp.items + (size_t)lane * sp.item_stride * kItemLists; P.item_count = sp.item_count + (size_t)lane * kItemLists; P.item_stride = sp.item_stride; // lane == nlanes: B
-    P.ckf = sp.ckf; P.cka = sp.cka; P.part = sp.part; P.first = sp.first; P.ckh = sp.ckh;
+    P.ckf = sp.ckf; P.cka = sp.cka; P.part = sp.part; P.first = sp.first; P.ckh = sp.ckh; P.zeros = sp.ckh + sp.zeros_off;
     for (P.s_first = 0; P.s_first < c->G.nscales && c->G.sw[P.s_first] >= 64; P.s_first++) {} // first narrow scale
     if (c->dither) {
         const uint32_t l = lane < c->nlanes ? lane : 0;

@@ -269,6 +269,7 @@ __device__ __forceinline__ void sparse_v2_body(const SparseParams &P, const int 
         for (int q = 0; q < 6; q++) acc[q] = ld_at<double>(ca + (size_t)q * W, l8);
     }
     auto hbase = [&](int g) -> const float * { // plane 0 of group g for this wave: the candidate's if it wrote these columns, else B's
+        if (g >= H4) return P.zeros; // below the image: the prefetch stays unconditional (no per-iteration zeroing of its registers)
         const int sl = uni((int)s_slot[wv][g]);
         return sl >= 0 ? h_own + (size_t)sl * 9 * W4 : h_b + (size_t)g * 9 * W4;
     };
@@ -300,17 +301,17 @@ __device__ __forceinline__ void sparse_v2_body(const SparseParams &P, const int 
             _Pragma("unroll") for (int q = 0; q < 6; q++) ck_a[(size_t)q * W] = acc[q];                                       \
             ck_f += (size_t)18 * W; ck_a += (size_t)6 * W;                                                                    \
         }                                                                                                                     \
-        if (g + 1 < H4) { const float *hp = hbase(g + 1); NXT[0] = ld_at<float4>(hp, l16); NXT[1] = ld_at<float4>(hp + W4, l16); NXT[2] = ld_at<float4>(hp + 2 * W4, l16); } \
-        else { NXT[0] = zero4; NXT[1] = zero4; NXT[2] = zero4; }                                                              \
-        /* inputs of the maps of row group g-1, consumed after the recurrence steps below */                                  \
-        float4 c_m1 = zero4, c_sd1 = zero4, c_a1 = zero4, c_x = zero4;                                                        \
-        double2 c_ra = make_double2(1.0, 1.0), c_rb = c_ra;                                                                   \
-        if (g >= 1) {                                                                                                         \
-            const size_t go = (size_t)(g - 1) * W4;                                                                           \
+        { const float *hp = hbase(g + 1); NXT[0] = ld_at<float4>(hp, l16); NXT[1] = ld_at<float4>(hp + W4, l16); NXT[2] = ld_at<float4>(hp + 2 * W4, l16); } \
+        /* inputs of the maps of row group g-1, consumed after the recurrence steps below (g = 0: group 0's, unused) */        \
+        float4 c_m1, c_sd1, c_a1, c_x;                                                                                        \
+        double2 c_ra, c_rb;                                                                                                   \
+        {                                                                                                                     \
+            const int gm = g >= 1 ? g - 1 : 0;                                                                                \
+            const size_t go = (size_t)gm * W4;                                                                                \
             c_m1 = ld_at<float4>(m1_b + go, l16); c_sd1 = ld_at<float4>(sd1_b + go, l16); c_a1 = ld_at<float4>(a1_b + go, l16); \
             c_ra = ld_at<double2>(r1_b + go, l32); c_rb = ld_at<double2>(r1_b + go + 2, l32);                                 \
-            const int sl = uni((int)s_slot[wv][g - 1]);                                                                       \
-            c_x = ld_at<float4>(sl >= 0 ? x_own + (size_t)sl * 3 * W4 : x_b + (size_t)(g - 1) * 3 * W4, l16);                 \
+            const int sl = uni((int)s_slot[wv][gm]);                                                                          \
+            c_x = ld_at<float4>(sl >= 0 ? x_own + (size_t)sl * 3 * W4 : x_b + (size_t)gm * 3 * W4, l16);                      \
         }                                                                                                                     \
         float outp[3][4];                                                                                                     \
         _Pragma("unroll") for (int p = 0; p < 3; p++) {                                                                       \
@@ -323,6 +324,8 @@ __device__ __forceinline__ void sparse_v2_body(const SparseParams &P, const int 
             SNES_VSTEP(tx.x + CUR[p].z, sa[p], sb[p], outp[p][2])                                                             \
             SNES_VSTEP(tx.y + CUR[p].w, sb[p], sa[p], outp[p][3])                                                             \
         }                                                                                                                     \
+        /* a1 stays binary32 until the maps: converted where it is loaded, the iteration would open with a wait on memory */  \
+        asm volatile("" : "+v"(c_a1.x), "+v"(c_a1.y), "+v"(c_a1.z), "+v"(c_a1.w));                                            \
         if (g >= 1) {                                                                                                         \
             const float m1v[4] = {c_m1.x, c_m1.y, c_m1.z, c_m1.w}, sd1v[4] = {c_sd1.x, c_sd1.y, c_sd1.z, c_sd1.w};              \
             const float a1v[4] = {c_a1.x, c_a1.y, c_a1.z, c_a1.w}, i2v[4] = {c_x.x, c_x.y, c_x.z, c_x.w};                     \
