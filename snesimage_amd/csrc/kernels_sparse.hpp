@@ -390,7 +390,9 @@ __device__ __forceinline__ void sparse_down_body(const SparseParams &P, int only
         const int Ws = G.sw[s], Wp = G.sw[s - 1];
         const int n = M->ngroups[s];
         for (int i = part0 * 256 + t; i < n * 4 * Ws; i += 256 * nparts) {
-            const int j = i / (4 * Ws), r = (i / Ws) & 3, x = i % Ws;
+            // consecutive lanes walk a group the way its planes are laid out (x & 3, then the row, then the column quad): every
+            // store instruction below writes whole lines
+            const int j = i / (4 * Ws), rem = i - j * 4 * Ws, r = (rem >> 2) & 3, x = ((rem >> 4) << 2) | (rem & 3);
             const int g = M->glist[P.S.goff[s] + j];
             const int y = 4 * g + r;
             float v[3];
@@ -415,10 +417,11 @@ __device__ __forceinline__ void sparse_down_body(const SparseParams &P, int only
                 const short sl = M->gslot[P.S.goff[s - 1] + gp];
                 const float *grp = sl >= 0 ? mine + P.S.off_lin[s - 1] + (size_t)sl * 12 * Wp : basep + P.S.off_lin[s - 1] + (size_t)gp * 12 * Wp;
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    const float *r0 = grp + (size_t)(c * 4 + rp) * Wp, *r1 = r0 + Wp;
+                for (int c = 0; c < 3; c++) { // linear planes in the C4 order: [column quad][row][column & 3]
+                    const float *q0 = grp + (size_t)c * 4 * Wp + (size_t)((2 * x) >> 2) * 16 + rp * 4 + ((2 * x) & 3);
+                    const float2 a = *reinterpret_cast<const float2 *>(q0), b = *reinterpret_cast<const float2 *>(q0 + 4);
                     float sum = 0.0f;
-                    sum += r0[2 * x]; sum += r0[2 * x + 1]; sum += r1[2 * x]; sum += r1[2 * x + 1];
+                    sum += a.x; sum += a.y; sum += b.x; sum += b.y;
                     v[c] = sum * 0.25f;
                 }
             }
@@ -429,7 +432,7 @@ __device__ __forceinline__ void sparse_down_body(const SparseParams &P, int only
             const float xyb[3] = {X, Y, B};
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                ol[(size_t)(c * 4 + r) * Ws + x] = v[c];
+                ol[(size_t)c * 4 * Ws + (size_t)(x >> 2) * 16 + r * 4 + (x & 3)] = v[c];
                 oc[(size_t)c * 4 * Ws + (size_t)(x >> 2) * 16 + r * 4 + (x & 3)] = xyb[c];
                 orr[(size_t)c * 4 * Ws + (size_t)x * 4 + r] = xyb[c];
             }
@@ -450,7 +453,7 @@ __device__ __forceinline__ void base_store(const SparseParams &P, float *mine, i
     float *oc = mine + P.S.off_xybC[s] + (size_t)g * 12 * Ws, *orr = mine + P.S.off_xybR[s] + (size_t)g * 12 * Ws;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        if (keep_lin) ol[(size_t)(c * 4 + r) * Ws + X] = lin[c];
+        if (keep_lin) ol[(size_t)c * 4 * Ws + (size_t)(X >> 2) * 16 + r * 4 + (X & 3)] = lin[c];
         oc[(size_t)c * 4 * Ws + (size_t)(X >> 2) * 16 + r * 4 + (X & 3)] = xyb[c];
         orr[(size_t)c * 4 * Ws + (size_t)X * 4 + r] = xyb[c];
     }
