@@ -389,10 +389,11 @@ __device__ __forceinline__ void sparse_down_body(const SparseParams &P, int only
     for (int s = s_lo; s < s_hi; s++) {
         const int Ws = G.sw[s], Wp = G.sw[s - 1];
         const int n = M->ngroups[s];
+        const int lw4 = 31 - __clz(4 * Ws); // the scales' widths are powers of two (W = 256)
         for (int i = part0 * 256 + t; i < n * 4 * Ws; i += 256 * nparts) {
             // consecutive lanes walk a group the way its planes are laid out (x & 3, then the row, then the column quad): every
             // store instruction below writes whole lines
-            const int j = i / (4 * Ws), rem = i - j * 4 * Ws, r = (rem >> 2) & 3, x = ((rem >> 4) << 2) | (rem & 3);
+            const int j = i >> lw4, rem = i & (4 * Ws - 1), r = (rem >> 2) & 3, x = ((rem >> 4) << 2) | (rem & 3);
             const int g = M->glist[P.S.goff[s] + j];
             const int y = 4 * g + r;
             float v[3];
