@@ -8,8 +8,9 @@
 //     block differs: B's H pass leaves that state behind (18 floats per row, channel and block boundary: `ckh`), the
 //     scan lists the work items per (scale, first block), and every wave of sparse_h2_body starts all its rows at the
 //     same block.  On the BASELINE workload this removes ~40 % of the H pass's steps and of its output traffic.
-//   * H output leaves a wave as 256-byte runs (16 columns x 4 rows of one plane, staged through LDS) instead of the
-//     64-byte runs one column quad gives: every store instruction writes whole 128-byte lines.
+//   * H output leaves a wave as 128-byte lines (8 columns x 4 rows of one plane, staged through LDS) instead of the
+//     64-byte runs one column quad gives; the staging is kept that small (12 KB per wave) because the kernel is a chain
+//     of dependent iterations per wave and lives on the number of waves a CU holds.
 //   * At scale 0 the H pass also stores the XYB value it looked up for every pixel of a changed group (and B's H pass
 //     does for the whole of B), so the V pass reads its map input `img2` from a plane at every scale: it no longer
 //     touches the pack, the palette table or the won-pixel bitmap, and has one body for all scales.
@@ -48,13 +49,20 @@ namespace snes {
 // (the "right" taps in[n+4]) and yields the outputs of quad g-1; the five-slot register ring keeps quads g-3..g+1.
 // S0: scale 0 — the candidate's pixels come from the pack (win test) instead of an XYB plane.
 // bx / gx: the block's index and count among the blocks of its list (blockIdx.x / gridDim.x unless the caller remaps blocks)
+// LDS of one block (= one wave), shared by the two instantiations of the body (a block runs one of them; declared inside the
+// template each instantiation would take its own copy and the kernel would hold both: 32 KB per wave, five waves per CU)
+struct H2Shared {
+    float lut[3 * 256];                                         // scale 0: XYB of the palette entries
+    __attribute__((aligned(16))) float out[16 * (4 * 32 + 4)];  // staging: per item [plane][8 columns][4 rows] + pad
+    long long hbase[16], xbase[16];                             // per item: float offset of its H output / XYB planes inside P.store, -1 = no item
+};
 template <bool S0>
-__device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int list, const int bx, const int gx) {
+__device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int list, const int bx, const int gx, H2Shared &sh) {
     constexpr int NP = S0 ? 4 : 3;        // staged planes: the three H outputs (+ the XYB input at scale 0)
-    constexpr int ISTR = NP * 64 + 4;     // staging words per item; the pad spreads the quads' rows over the LDS banks
-    __shared__ float s_lut[S0 ? 3 * 256 : 1];
-    __shared__ __attribute__((aligned(16))) float s_out[16 * ISTR];
-    __shared__ long long s_hbase[16], s_xbase[16]; // per item: float offset of its H output / XYB planes inside P.store, -1 = no item
+    constexpr int PW = 32;                // staged floats per plane: 8 columns x 4 rows = one 128-byte line of the XT4 / R4 layouts
+    constexpr int ISTR = NP * PW + 4;     // staging words per item; the pad spreads the quads' rows over the LDS banks
+    float *const s_lut = sh.lut, *const s_out = sh.out;
+    long long *const s_hbase = sh.hbase, *const s_xbase = sh.xbase;
     const Geom &G = P.G;
     const int s = list / kColBuckets, cb = list % kColBuckets;
     const int W = G.sw[s], H = G.sh[s];
@@ -160,24 +168,23 @@ __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int 
                     if ((q & 1) == 0) { SNES_HSTEP(s0, sa[0], sb[0], outp[0][q]) SNES_HSTEP(s1, sa[1], sb[1], outp[1][q]) SNES_HSTEP(s2, sa[2], sb[2], outp[2][q]) }
                     else { SNES_HSTEP(s0, sb[0], sa[0], outp[0][q]) SNES_HSTEP(s1, sb[1], sa[1], outp[1][q]) SNES_HSTEP(s2, sb[2], sa[2], outp[2][q]) }
                 }
-                if (g > gs) { // outputs of quad g-1 (those of quad gs-1 are B's and stay unwritten): stage [plane][column % 16][row]
-                    float *so = s_out + (lane >> 2) * ISTR + (((g - 1) & 3) << 4) + r;
+                if (g > gs) { // outputs of quad g-1 (those of quad gs-1 are B's and stay unwritten): stage [plane][column % 8][row]
+                    float *so = s_out + (lane >> 2) * ISTR + (((g - 1) & 1) << 4) + r;
 #pragma unroll
-                    for (int p = 0; p < 3; p++) { so[p * 64 + 0] = outp[p][0]; so[p * 64 + 4] = outp[p][1]; so[p * 64 + 8] = outp[p][2]; so[p * 64 + 12] = outp[p][3]; }
-                    if (S0) { so[3 * 64 + 0] = r2[ul].x; so[3 * 64 + 4] = r2[ul].y; so[3 * 64 + 8] = r2[ul].z; so[3 * 64 + 12] = r2[ul].w; }
-                    if ((g & 3) == 0) { // 16 columns complete: one store instruction per item = its NP planes as 256-byte runs
+                    for (int p = 0; p < 3; p++) { so[p * PW + 0] = outp[p][0]; so[p * PW + 4] = outp[p][1]; so[p * PW + 8] = outp[p][2]; so[p * PW + 12] = outp[p][3]; }
+                    if (S0) { so[3 * PW + 0] = r2[ul].x; so[3 * PW + 4] = r2[ul].y; so[3 * PW + 8] = r2[ul].z; so[3 * PW + 12] = r2[ul].w; }
+                    if ((g & 1) == 0) { // 8 columns complete (gs and W/4 are even): one store instruction per two items = their NP planes as 128-byte lines
                         __syncthreads();
-                        const int x0 = (g - 4) << 2; // first column of the run
-                        const int p = lane >> 4, c = lane & 15;
+                        const int x0 = (g - 2) << 2; // first column of the run
+                        const int half = lane >> 5, l = lane & 31, p = l >> 3, c = l & 7;
                         // float offset of this lane's 16 bytes behind the item's base: plane p of the H output (XT4 block of x0), or the XYB plane (R4)
                         const uint32_t o_l = (S0 && p == 3) ? (uint32_t)(x0 << 2) + (uint32_t)(c << 2) : (uint32_t)p * 4u * (uint32_t)W + (uint32_t)((x0 >> 6) << 8) + (uint32_t)((x0 & 63) << 2) + (uint32_t)(c << 2);
 #pragma unroll 4
-                        for (int m = 0; m < 16; m++) {
-                            const long long hb = s_hbase[m]; // wave-uniform
-                            if (hb < 0) continue;
-                            if (lane < NP * 16) {
-                                const float4 v = *reinterpret_cast<const float4 *>(s_out + m * ISTR + lane * 4);
-                                float *dst = P.store + ((S0 && p == 3) ? s_xbase[m] : hb) + o_l;
+                        for (int m = 0; m < 16; m += 2) {
+                            const long long hb = s_hbase[m + half];
+                            if (hb >= 0 && l < NP * 8) {
+                                const float4 v = *reinterpret_cast<const float4 *>(s_out + (m + half) * ISTR + l * 4);
+                                float *dst = P.store + ((S0 && p == 3) ? s_xbase[m + half] : hb) + o_l;
                                 *reinterpret_cast<float4 *>(dst) = v;
                             }
                         }
@@ -371,7 +378,8 @@ __device__ __forceinline__ void sparse_v2_body(const SparseParams &P, const int 
 __device__ __forceinline__ void sparse_h2_dispatch(const SparseParams &P, const int list, const int bx, const int gx) {
     const int s = list / kColBuckets;
     if (s >= P.G.nscales || P.G.sw[s] < 64 || (list % kColBuckets) >= (P.G.sw[s] >> 6)) return;
-    if (s == 0) sparse_h2_body<true>(P, list, bx, gx); else sparse_h2_body<false>(P, list, bx, gx);
+    __shared__ H2Shared sh;
+    if (s == 0) sparse_h2_body<true>(P, list, bx, gx, sh); else sparse_h2_body<false>(P, list, bx, gx, sh);
 }
 __global__ __launch_bounds__(64) void k_sparse_h2(SparseParams P) { sparse_h2_dispatch(P, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x); }
 __global__ __launch_bounds__(256, 4) void k_sparse_v2(SparseParams P) { if ((int)blockIdx.y < P.G.nscales && P.G.sw[blockIdx.y] >= 64) sparse_v2_body<false>(P, (int)blockIdx.y, (int)blockIdx.x); }
