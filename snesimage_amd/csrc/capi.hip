@@ -139,7 +139,7 @@ struct snesimage_ctx {
     struct Sparse {
         bool lpt = true; // V pass in descending sweep length (SNES_LPT=0: as listed)
         bool counters_cleared = false; // k_prep cleared B's counters for the current pack
-        uint32_t hgrid = 2048; // most blocks per scale of k_sparse_h (grid-stride beyond)
+        uint32_t hgrid = 8192; // most blocks per scale of k_sparse_h (grid-stride beyond)
         bool enabled = false, side = true; uint32_t min_n = 64; uint32_t cap = 0; // cap = candidates per lane the arrays were sized for
         SparseGeom S{};
         float *store = nullptr, *cand_tab = nullptr, *cand_lab = nullptr, *ckf = nullptr, *ckh = nullptr; long long zeros_off = 0; uint32_t *bitmap = nullptr; double *cka = nullptr, *part = nullptr;

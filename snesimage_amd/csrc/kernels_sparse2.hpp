@@ -200,6 +200,24 @@ __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int 
 // Same checkpoint records, tail ring and pooling as sparse_v_body (kernels_sparse.hpp); W >= 64 only.
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 template <typename T> __device__ __forceinline__ T ld_at(const void *sbase, uint32_t voff) { return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(sbase) + voff); }
+// Buffer loads: a wave-uniform descriptor (four SGPRs), a 32-bit lane offset and a scalar byte offset.  Written as plain
+// pointer arithmetic the compiler re-associates (uniform base + group offset) + lane offset into (base + lane offset) + group
+// offset: a 64-bit VGPR pair per array and a 64-bit vector add per load.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p) { // p must be wave-uniform; the readfirstlanes make that provable (no waterfall loops around the loads)
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned long long u = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(u), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld4(rsrc_t r, uint32_t voff, uint32_t soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ double2 buf_ld2d(rsrc_t r, uint32_t voff, uint32_t soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_double2(__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z));
+}
 
 // BASE: the image B itself — every group is its own, the sweep starts at the top with a zero state and leaves the
 // checkpoint records behind (record g: state before group iteration g and pooling sums of rows < 4g-4; record H/4+1: final sums).
@@ -211,7 +229,8 @@ __device__ __forceinline__ void sparse_v2_body(const SparseParams &P, const int 
     double (*red)[6] = reinterpret_cast<double (*)[6]>(s_raw);
     static_assert(sizeof(s_raw) >= 256 * 6 * sizeof(double), "reduction scratch must fit the tail ring");
     const Geom &G = P.G;
-    const int W = G.sw[s], H = G.sh[s], H4 = H >> 2;
+    // (the geometry arrays are indexed dynamically: without the readfirstlanes their values count as divergent)
+    const int W = uni(G.sw[s]), H = uni(G.sh[s]), H4 = H >> 2;
     const int t = threadIdx.x, lane = t & 63;
     const int wv = uni(t >> 6);
     const int wpp = W >> 6, ppw = 4 / wpp; // waves per pair, pairs per block
@@ -241,16 +260,17 @@ __device__ __forceinline__ void sparse_v2_body(const SparseParams &P, const int 
     const size_t ns = (size_t)W * H;
     const float *store_k = P.store + (size_t)k * P.S.cand_stride, *store_b = P.store + (size_t)P.base * P.S.cand_stride;
     // wave-uniform bases; per group: + g * (36 W | 12 W | 4 W) floats
-    const float *h_own = store_k + P.S.off_hout[s] + (size_t)(ch * 3) * 4 * W + ((size_t)(xw >> 6) << 8);
-    const float *h_b = store_b + P.S.off_hout[s] + (size_t)(ch * 3) * 4 * W + ((size_t)(xw >> 6) << 8);
-    const float *x_own = store_k + P.S.off_xybR[s] + (size_t)ch * 4 * W + (size_t)xw * 4;
-    const float *x_b = store_b + P.S.off_xybR[s] + (size_t)ch * 4 * W + (size_t)xw * 4;
-    const float *m1_b = P.mu1R4 + G.src_off[s] + (size_t)ch * ns + (size_t)xw * 4;
-    const float *sd1_b = P.sd1R4 + G.src_off[s] + (size_t)ch * ns + (size_t)xw * 4;
-    const float *a1_b = P.a1R4 + G.src_off[s] + (size_t)ch * ns + (size_t)xw * 4;
-    const double *r1_b = P.r1R4 + G.src_off[s] + (size_t)ch * ns + (size_t)xw * 4;
+    const rsrc_t h_own = make_rsrc(store_k + P.S.off_hout[s] + (size_t)(ch * 3) * 4 * W + ((size_t)(xw >> 6) << 8));
+    const rsrc_t h_b = make_rsrc(store_b + P.S.off_hout[s] + (size_t)(ch * 3) * 4 * W + ((size_t)(xw >> 6) << 8));
+    const rsrc_t h_zero = make_rsrc(P.zeros);
+    const rsrc_t x_own = make_rsrc(store_k + P.S.off_xybR[s] + (size_t)ch * 4 * W + (size_t)xw * 4);
+    const rsrc_t x_b = make_rsrc(store_b + P.S.off_xybR[s] + (size_t)ch * 4 * W + (size_t)xw * 4);
+    const rsrc_t m1_b = make_rsrc(P.mu1R4 + G.src_off[s] + (size_t)ch * ns + (size_t)xw * 4);
+    const rsrc_t sd1_b = make_rsrc(P.sd1R4 + G.src_off[s] + (size_t)ch * ns + (size_t)xw * 4);
+    const rsrc_t a1_b = make_rsrc(P.a1R4 + G.src_off[s] + (size_t)ch * ns + (size_t)xw * 4);
+    const rsrc_t r1_b = make_rsrc(P.r1R4 + G.src_off[s] + (size_t)ch * ns + (size_t)xw * 4);
     const uint32_t l4 = (uint32_t)lane << 2, l8 = (uint32_t)lane << 3, l16 = (uint32_t)lane << 4, l32 = (uint32_t)lane << 5;
-    const uint32_t W4 = (uint32_t)W * 4u; // floats per (plane, group)
+    const uint32_t W16 = (uint32_t)W * 16u; // bytes per (plane, group): 4 W floats
 
     const float n2_0 = P.K.n2[0], n2_1 = P.K.n2[1], n2_2 = P.K.n2[2];
     const float d1_0 = P.K.d1[0], d1_1 = P.K.d1[1], d1_2 = P.K.d1[2];
@@ -275,26 +295,34 @@ __device__ __forceinline__ void sparse_v2_body(const SparseParams &P, const int 
 #pragma unroll
         for (int q = 0; q < 6; q++) acc[q] = ld_at<double>(ca + (size_t)q * W, l8);
     }
-    auto hbase = [&](int g) -> const float * { // plane 0 of group g for this wave: the candidate's if it wrote these columns, else B's
-        if (g >= H4) return P.zeros; // below the image: the prefetch stays unconditional (no per-iteration zeroing of its registers)
-        const int sl = uni((int)s_slot[wv][g]);
-        return sl >= 0 ? h_own + (size_t)sl * 9 * W4 : h_b + (size_t)g * 9 * W4;
-    };
+    // the three planes of group g for this wave: the candidate's if it wrote these columns, else B's; zeros below the image
+    // (the prefetch stays unconditional: no per-iteration zeroing of its registers)
+#define SNES_HLOAD(GG, DST)                                                                                                   \
+    {                                                                                                                         \
+        const int gg_ = (GG);                                                                                                 \
+        const bool below_ = gg_ >= H4;                                                                                        \
+        const int sl_ = uni((int)s_slot[wv][below_ ? 0 : gg_]);                                                               \
+        const rsrc_t r_ = below_ ? h_zero : (sl_ >= 0 ? h_own : h_b);                                                         \
+        const uint32_t so_ = below_ ? 0u : (uint32_t)(sl_ >= 0 ? sl_ : gg_) * 9u * W16;                                       \
+        DST[0] = buf_ld4(r_, l16, so_); DST[1] = buf_ld4(r_, l16, so_ + W16); DST[2] = buf_ld4(r_, l16, so_ + 2u * W16);      \
+    }
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // Tail ring slots are relative to gs: group gs+r keeps its xy half in slot r mod 2 and its zw half in slot r mod 3.
     float2 *ring_xy = reinterpret_cast<float2 *>(s_raw) + t;                             // + (slot*3 + plane) * 256
     float2 *ring_zw = reinterpret_cast<float2 *>(s_raw + 2 * 3 * 256 * sizeof(float2)) + t;
     float4 bufA[3], bufB[3];
+    float4 t1[3] = {zero4, zero4, zero4}, t2[3] = {zero4, zero4, zero4}, t3[3] = {zero4, zero4, zero4};
+#pragma unroll
+    for (int p = 0; p < 3; p++) { bufA[p] = zero4; bufB[p] = zero4; }
+    if (gs <= H4) {
+        if (gs < H4) SNES_HLOAD(gs, bufA)
+        if (gs - 1 >= 0) SNES_HLOAD(gs - 1, t1)
+        if (gs - 2 >= 0) SNES_HLOAD(gs - 2, t2)
+        if (gs - 3 >= 0) SNES_HLOAD(gs - 3, t3)
+    }
 #pragma unroll
     for (int p = 0; p < 3; p++) {
-        float4 g1 = zero4, g2 = zero4, g3 = zero4;
-        bufA[p] = zero4; bufB[p] = zero4;
-        if (gs <= H4) {
-            if (gs < H4) bufA[p] = ld_at<float4>(hbase(gs) + (size_t)p * W4, l16);
-            if (gs - 1 >= 0) g1 = ld_at<float4>(hbase(gs - 1) + (size_t)p * W4, l16);
-            if (gs - 2 >= 0) g2 = ld_at<float4>(hbase(gs - 2) + (size_t)p * W4, l16);
-            if (gs - 3 >= 0) g3 = ld_at<float4>(hbase(gs - 3) + (size_t)p * W4, l16);
-        }
+        const float4 g1 = t1[p], g2 = t2[p], g3 = t3[p];
         ring_xy[(1 * 3 + p) * 256] = make_float2(g1.x, g1.y); ring_zw[(2 * 3 + p) * 256] = make_float2(g1.z, g1.w); // r = -1
         ring_xy[(0 * 3 + p) * 256] = make_float2(g2.x, g2.y); ring_zw[(1 * 3 + p) * 256] = make_float2(g2.z, g2.w); // r = -2
         ring_zw[(0 * 3 + p) * 256] = make_float2(g3.z, g3.w);                                                       // r = -3
@@ -308,17 +336,17 @@ __device__ __forceinline__ void sparse_v2_body(const SparseParams &P, const int 
             _Pragma("unroll") for (int q = 0; q < 6; q++) ck_a[(size_t)q * W] = acc[q];                                       \
             ck_f += (size_t)18 * W; ck_a += (size_t)6 * W;                                                                    \
         }                                                                                                                     \
-        { const float *hp = hbase(g + 1); NXT[0] = ld_at<float4>(hp, l16); NXT[1] = ld_at<float4>(hp + W4, l16); NXT[2] = ld_at<float4>(hp + 2 * W4, l16); } \
+        SNES_HLOAD(g + 1, NXT)                                                                                                \
         /* inputs of the maps of row group g-1, consumed after the recurrence steps below (g = 0: group 0's, unused) */        \
         float4 c_m1, c_sd1, c_a1, c_x;                                                                                        \
         double2 c_ra, c_rb;                                                                                                   \
         {                                                                                                                     \
             const int gm = g >= 1 ? g - 1 : 0;                                                                                \
-            const size_t go = (size_t)gm * W4;                                                                                \
-            c_m1 = ld_at<float4>(m1_b + go, l16); c_sd1 = ld_at<float4>(sd1_b + go, l16); c_a1 = ld_at<float4>(a1_b + go, l16); \
-            c_ra = ld_at<double2>(r1_b + go, l32); c_rb = ld_at<double2>(r1_b + go + 2, l32);                                 \
+            const uint32_t go = (uint32_t)gm * W16;                                                                           \
+            c_m1 = buf_ld4(m1_b, l16, go); c_sd1 = buf_ld4(sd1_b, l16, go); c_a1 = buf_ld4(a1_b, l16, go);                    \
+            c_ra = buf_ld2d(r1_b, l32, 2u * go); c_rb = buf_ld2d(r1_b, l32 + 16u, 2u * go);                                   \
             const int sl = uni((int)s_slot[wv][gm]);                                                                          \
-            c_x = ld_at<float4>(sl >= 0 ? x_own + (size_t)sl * 3 * W4 : x_b + (size_t)gm * 3 * W4, l16);                      \
+            c_x = buf_ld4(sl >= 0 ? x_own : x_b, l16, (uint32_t)(sl >= 0 ? sl : gm) * 3u * W16);                              \
         }                                                                                                                     \
         float outp[3][4];                                                                                                     \
         _Pragma("unroll") for (int p = 0; p < 3; p++) {                                                                       \
@@ -349,6 +377,7 @@ __device__ __forceinline__ void sparse_v2_body(const SparseParams &P, const int 
         SNES_V2GROUP(bufB, bufA)
     }
 #undef SNES_V2GROUP
+#undef SNES_HLOAD
     if (BASE && active) { // final record (H4 + 1): the pooling sums of the whole column
 #pragma unroll
         for (int q = 0; q < 6; q++) ck_a[(size_t)q * W] = acc[q];
@@ -382,7 +411,7 @@ __device__ __forceinline__ void sparse_h2_dispatch(const SparseParams &P, const 
     if (s == 0) sparse_h2_body<true>(P, list, bx, gx, sh); else sparse_h2_body<false>(P, list, bx, gx, sh);
 }
 __global__ __launch_bounds__(64) void k_sparse_h2(SparseParams P) { sparse_h2_dispatch(P, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x); }
-__global__ __launch_bounds__(256, 4) void k_sparse_v2(SparseParams P) { if ((int)blockIdx.y < P.G.nscales && P.G.sw[blockIdx.y] >= 64) sparse_v2_body<false>(P, (int)blockIdx.y, (int)blockIdx.x); }
+__global__ __launch_bounds__(256, 5) void k_sparse_v2(SparseParams P) { if ((int)blockIdx.y < P.G.nscales && P.G.sw[blockIdx.y] >= 64) sparse_v2_body<false>(P, (int)blockIdx.y, (int)blockIdx.x); }
 // B: the wide scales in this body (grid.y = scale), the narrow ones in the general one (grid.y = scale - s_first), two launches:
 // one kernel holding both bodies would take the larger register allocation for every block
 __global__ __launch_bounds__(256) void k_sparse_v2_base(SparseParams P) { if ((int)blockIdx.y < P.G.nscales && P.G.sw[blockIdx.y] >= 64) sparse_v2_body<true>(P, (int)blockIdx.y, (int)blockIdx.x); }
