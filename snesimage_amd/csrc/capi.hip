@@ -145,7 +145,7 @@ struct snesimage_ctx {
         float *store = nullptr, *cand_tab = nullptr, *cand_lab = nullptr, *ckf = nullptr, *ckh = nullptr; long long zeros_off = 0; uint32_t *bitmap = nullptr; double *cka = nullptr, *part = nullptr;
         CandMeta *meta = nullptr; unsigned int *items = nullptr; int *item_count = nullptr; long long item_stride = 0; int *order = nullptr, *first = nullptr;
         uint4 *plist = nullptr; int *plist_count = nullptr; bool plist_valid = false;
-        hipStream_t base_stream = nullptr; hipEvent_t ev_base_in = nullptr, ev_base_done = nullptr; // B's H and V passes run beside the candidates' scan/down/H
+        hipStream_t base_stream = nullptr; hipEvent_t ev_base_in = nullptr, ev_base_h = nullptr, ev_base_done = nullptr; // B's H and V passes run beside the candidates' scan/down/H
         // --dither (RGB distance): B dithered once per slot (k_dither MODE 1) and the candidates resumed from its checkpoints (MODE 2)
         uint8_t *dmaps = nullptr, *dmapsC4 = nullptr; // [lane][cap][W*H] candidates' palette_maps, row-major and C4
         uint8_t *bmap = nullptr, *bmapC4 = nullptr, *bcand = nullptr; unsigned long long *dpack = nullptr; double *ckd = nullptr; uint32_t slot_ci = 0;
@@ -454,6 +454,7 @@ int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
         HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         HIPCHK(hipStreamCreateWithPriority(&sp.base_stream, hipStreamNonBlocking, prio_hi));
         HIPCHK(hipEventCreateWithFlags(&sp.ev_base_in, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&sp.ev_base_h, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sp.ev_base_done, hipEventDisableTiming));
     }
     HIPCHK(dmalloc(&sp.item_count, sizeof(int) * (kItemLists * (c->nlanes + 1) + 1))); // + the contested-pixel count, right behind B's counters
@@ -521,7 +522,6 @@ int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si) {
         hipLaunchKernelGGL(k_build_plist, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, win_pack, (int)c->npx, sp.plist, sp.plist_count);
         SparseParams P = sparse_params(c, c->nlanes); // B has its own item list and counters
         P.is_base = 1; P.ncand = 1; P.k0 = P.base;
-        hipLaunchKernelGGL(k_sparse_scan, dim3(1), dim3(1024), 0, c->stream, P);
         hipLaunchKernelGGL(k_base_down, dim3((unsigned)((G.W / 32) * (G.H / 32))), dim3(256), 0, c->stream, P); // B: every row of every scale
         // B's H and V passes are long single-image sweeps (latency-bound); they run on their own stream beside the
         // candidates' scan / downscale / H pass, which only need B's linear-RGB rows.  The candidates' V pass waits for them.
@@ -529,9 +529,11 @@ int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si) {
         // add cross-queue waits.)
         hipStream_t bs = sp.side ? sp.base_stream : c->stream;
         if (sp.side) { HIPCHK(hipEventRecord(sp.ev_base_in, c->stream)); HIPCHK(hipStreamWaitEvent(bs, sp.ev_base_in, 0)); }
+        hipLaunchKernelGGL(k_sparse_scan, dim3(1), dim3(1024), 0, bs, P); // B's work items (every group, from column 0): only B's own sweeps read them
         // wide scales: B rows start at column 0 (list s*kColBuckets) and leave the per-block H checkpoints and the scale-0 XYB plane
         hipLaunchKernelGGL(k_sparse_h2, dim3((unsigned)((G.sh[0] / 4 * 3 + 15) / 16), (unsigned)(P.s_first * kColBuckets)), dim3(64), 0, bs, P);
-        if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((G.sh[P.s_first] / 4 * 3 + 15) / 16), (unsigned)(G.nscales * kColBuckets)), dim3(64), 0, bs, P);
+        if (sp.side) HIPCHK(hipEventRecord(sp.ev_base_h, bs)); // the candidates' H pass resumes from the block checkpoints this launch leaves
+        if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((G.sh[P.s_first] / 4 * 3 + 15) / 16), (unsigned)((G.nscales - P.s_first) * kColBuckets)), dim3(64), 0, bs, P);
         if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_v_base_narrow, dim3(3, (unsigned)(G.nscales - P.s_first)), dim3(256), 0, bs, P);
         if (P.s_first > 0) hipLaunchKernelGGL(k_sparse_v2_base, dim3(3, (unsigned)P.s_first), dim3(256), 0, bs, P);
         HIPCHK(hipGetLastError());
@@ -556,6 +558,9 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
         Dp.maps = const_cast<uint8_t *>(P.maps); Dp.mapsC4 = const_cast<uint8_t *>(P.mapsC4);
         Dp.W = (int)c->W; Dp.H = (int)c->H; Dp.sub_size = (int)c->sub_size; Dp.ncol = c->ncol; Dp.slot_ci = sp.slot_ci;
         Dp.first_group = sp.first; Dp.first_k0 = P.k0; Dp.ck_in = sp.ckd; Dp.bmap = sp.bmap; Dp.bmapC4 = sp.bmapC4;
+        if (c->sp.lpt) { // the resumed runs differ several-fold in length: longest first (the order is rebuilt for the V pass below)
+            hipLaunchKernelGGL(k_sparse_order, dim3(1), dim3(1024), 0, stream, P, sp.order + P.k0); Dp.order = sp.order + P.k0;
+        }
         if (c->sub_size == 15) hipLaunchKernelGGL((k_dither<false, 15, 2>), dim3(nc), dim3(128), 0, stream, Dp);
         else hipLaunchKernelGGL((k_dither<false, 0, 2>), dim3(nc), dim3(128), 0, stream, Dp);
         hipLaunchKernelGGL(k_dither_diff, dim3((nc + 15) / 16), dim3(1024), 0, stream, P); // changed groups = where the maps differ
@@ -566,16 +571,17 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     } else hipLaunchKernelGGL(k_sparse_scan, dim3((nc + 15) / 16), dim3(1024), 0, stream, P);
     hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P, 0);
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[1], stream));
+    if (sp.side) HIPCHK(hipStreamWaitEvent(stream, sp.ev_base_h, 0)); // B's H-pass checkpoints (a short list gets here before B's sweep is through)
     { size_t gx = ((size_t)nc * (G.sh[0] / 4) * 3 + 15) / 16; if (gx > sp.hgrid) gx = sp.hgrid; // grid-stride over the item quads
       hipLaunchKernelGGL(k_sparse_h2, dim3((unsigned)gx, (unsigned)(P.s_first * kColBuckets)), dim3(64), 0, stream, P);
-      if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((gx + 7) / 8), (unsigned)(G.nscales * kColBuckets)), dim3(64), 0, stream, P); }
+      if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((gx + 7) / 8), (unsigned)((G.nscales - P.s_first) * kColBuckets)), dim3(64), 0, stream, P); }
     if (sp.side || stream != c->stream) HIPCHK(hipStreamWaitEvent(stream, sp.side ? sp.ev_base_done : c->ev_ready, 0)); // checkpoints and H output of B
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[2], stream));
     if (c->sp.lpt) { hipLaunchKernelGGL(k_sparse_order, dim3(1), dim3(1024), 0, stream, P, sp.order + P.k0); P.order = sp.order + P.k0; }
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[3], stream));
     hipLaunchKernelGGL(k_sparse_v2, dim3(nc * 3, (unsigned)P.s_first), dim3(256), 0, stream, P);
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[4], stream)); // ev[3]..ev[4]: k_sparse_v2 alone
-    if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_v, dim3((nc * 3 + 7) / 8, (unsigned)G.nscales), dim3(256), 0, stream, P); // narrow scales: >= 8 pairs per block
+    if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_v, dim3((nc * 3 + 7) / 8, (unsigned)(G.nscales - P.s_first)), dim3(256), 0, stream, P); // narrow scales: >= 8 pairs per block
     hipLaunchKernelGGL(k_final_score, dim3((nc + 63) / 64), dim3(64), 0, stream, sp.part + (size_t)P.k0 * G.nscales * 18, (int)nc, G, d_errors, err_stride, err_offset, P.item_count, (int)kItemLists);
     if (c->dither) { // the lane remembers the map of its best candidate so far: the commit adopts the winner's instead of dithering again
         uint8_t *bm = lane == 0 ? c->d_bestmap : c->extra[lane - 1].d_bestmap; BestRec *br = lane == 0 ? c->d_bestrec : c->extra[lane - 1].d_bestrec;
@@ -896,7 +902,7 @@ void snesimage_destroy(snesimage_ctx *c) {
     dfree(c->d_cand); dfree(c->d_cand_sel); dfree(c->d_errs); dfree(c->d_errs_sel); dfree(c->d_inc_err); dfree(c->d_last); dfree(c->d_scratch_err); dfree(c->d_dummy_cand);
     for (auto &L : c->extra) { if (L.stream) (void)hipStreamSynchronize(L.stream); dfree(L.d_mapsC4); dfree(L.d_mapsR4); dfree(L.d_work); dfree(L.d_cand_tab); dfree(L.d_cand_lab); dfree(L.d_part); dfree(L.d_maps); dfree(L.d_mapsT); if (L.done) (void)hipEventDestroy(L.done); if (L.stream) (void)hipStreamDestroy(L.stream); }
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
-    { auto &q = c->sp; if (q.base_stream) { (void)hipStreamSynchronize(q.base_stream); (void)hipStreamDestroy(q.base_stream); (void)hipEventDestroy(q.ev_base_in); (void)hipEventDestroy(q.ev_base_done); } dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.order); dfree(q.first); dfree(q.cand_lab); dfree(q.bitmap); dfree(q.ckh);
+    { auto &q = c->sp; if (q.base_stream) { (void)hipStreamSynchronize(q.base_stream); (void)hipStreamDestroy(q.base_stream); (void)hipEventDestroy(q.ev_base_in); (void)hipEventDestroy(q.ev_base_h); (void)hipEventDestroy(q.ev_base_done); } dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.order); dfree(q.first); dfree(q.cand_lab); dfree(q.bitmap); dfree(q.ckh);
       dfree(q.dmaps); dfree(q.dmapsC4); dfree(q.bmap); dfree(q.bmapC4); dfree(q.bcand); dfree(q.dpack); dfree(q.ckd); }
     kmeans_free(c->km);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

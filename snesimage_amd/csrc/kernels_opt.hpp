@@ -60,6 +60,7 @@ struct DitherParams {
     const int *first_group;       // per candidate: 4-row group holding its first won pixel in raster order (H/4 if it wins nothing); P.k0 offsets the index
     int first_k0;
     const double *ck_in; const uint8_t *bmap, *bmapC4; // B's checkpoints and map (rows above the first group are B's)
+    const int *order;             // block b takes candidate order[b] (k_sparse_order: longest resumes first); nullptr = as listed
 };
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(NT) void k_dither(DitherParams P) {
     __shared__ uint8_t s_tile[1024];
     if (P.skip && *P.skip) return;
     const int j = threadIdx.x;
-    const int cand = blockIdx.x;
+    const int cand = (MODE == 2 && P.order) ? P.order[blockIdx.x] : (int)blockIdx.x;
     constexpr int W = 256; // snesimage_create admits no other width; a constant keeps the per-step index arithmetic to shifts
     const int H = P.H;
     const int sub_size = SUB ? SUB : P.sub_size;

@@ -350,17 +350,24 @@ __device__ __forceinline__ void dither_diff_body(const SparseParams &P) {
     if (live) {
         const uint32_t *mc = reinterpret_cast<const uint32_t *>(P.maps + (size_t)(k - P.k0) * G.W * G.H), *mb = reinterpret_cast<const uint32_t *>(P.bmap);
         const int y0 = min(4 * P.first[k], G.H);
-        for (int y = y0; y < G.H; y++) { // W = 256: 64 words per row
-            const uint32_t d = mc[y * 64 + lane] ^ mb[y * 64 + lane];
-            const unsigned long long m = __ballot(d != 0u);
-            if (m) {
-                const int l0 = __ffsll((long long)m) - 1;
-                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, l0);
-                const int x = 4 * l0 + ((__ffs((int)d0) - 1) >> 3);
-                if (lane == 0) s_gx[w][y >> 2] = min(s_gx[w][y >> 2], x);
-                mask |= 1ull << (y >> 2);
-                xmin = min(xmin, x);
-                won += __popcll(m); // (words, not pixels: only a statistic)
+        for (int yb = y0; yb < G.H; yb += 8) { // W = 256: 64 words per row; two groups' rows in flight (the loop is a chain of loads)
+            uint32_t dd[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int yy = min(yb + u, G.H - 1); dd[u] = mc[yy * 64 + lane] ^ mb[yy * 64 + lane]; } // (rows past the image are clamped here and dropped below)
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int y = yb + u;
+                const uint32_t d = y < G.H ? dd[u] : 0u;
+                const unsigned long long m = __ballot(d != 0u);
+                if (m) {
+                    const int l0 = __ffsll((long long)m) - 1;
+                    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, l0);
+                    const int x = 4 * l0 + ((__ffs((int)d0) - 1) >> 3);
+                    if (lane == 0) s_gx[w][y >> 2] = min(s_gx[w][y >> 2], x);
+                    mask |= 1ull << (y >> 2);
+                    xmin = min(xmin, x);
+                    won += __popcll(m); // (words, not pixels: only a statistic)
+                }
             }
         }
     }
@@ -533,8 +540,8 @@ __device__ __forceinline__ void sparse_h_body(const SparseParams &P) {
     __shared__ float s_lut[3][256];
     __shared__ float s_tr[3][64 * 5];
     const Geom &G = P.G;
-    const int list = blockIdx.y, s = list / kColBuckets; // one item list per (scale, first column block)
-    if (s >= G.nscales || s < P.s_first) return;
+    const int list = P.s_first * kColBuckets + (int)blockIdx.y, s = list / kColBuckets; // one item list per (scale, first column block); grid.y = the narrow scales' lists
+    if (s >= G.nscales) return;
     const int lane = threadIdx.x;
     const int count = P.item_count[list];
     if ((int)blockIdx.x * 16 >= count) return;
@@ -879,7 +886,7 @@ __device__ __forceinline__ void sparse_v_body(const SparseParams &P, const int s
     }
 }
 // candidates: every scale in one launch, flags decided at run time (see sparse_v_body)
-__global__ __launch_bounds__(256, 4) void k_sparse_v(SparseParams P) { if ((int)blockIdx.y >= P.s_first) sparse_v_body<false, 2, 2>(P, (int)blockIdx.y); }
+__global__ __launch_bounds__(256, 4) void k_sparse_v(SparseParams P) { sparse_v_body<false, 2, 2>(P, (int)blockIdx.y + P.s_first); } // grid.y = narrow scales
 // B: one launch as well, each scale in its specialised flavour
 __device__ __forceinline__ void sparse_v_base_body(const SparseParams &P) {
     const int s = (int)blockIdx.y;

@@ -526,6 +526,26 @@ def test_gpu_matches_golden(S, case):
     g.close()
 
 
+def test_short_lists_wait_for_the_base_image(S, img256_alpha, monkeypatch):
+    """A 64-candidate list reaches its H pass before B's H sweep (on the side stream) has left the block checkpoints the
+    candidates resume from: the launch must wait for them.  Many slots, one short list each, against the dense path."""
+    monkeypatch.setenv("SNES_SPARSE", "0")
+    dense = S.OptimizedImage(img256_alpha, 8, 15)
+    monkeypatch.setenv("SNES_SPARSE", "1")
+    sparse = S.OptimizedImage(img256_alpha, 8, 15)
+    dense.initialize_tiles()
+    dense.recalculate_palettes()
+    sparse.tile_palettes = dense.tile_palettes
+    sparse.palette = dense.palette
+    sparse.optimize()
+    for i in range(40):
+        sp, si = i % 8, (7 * i) % 15
+        cand = S.random_candidates(100 + i, sp * 15 + si, 64)
+        assert np.array_equal(dense.score_candidates(sp, si, cand), sparse.score_candidates(sp, si, cand)), (sp, si)
+    dense.close()
+    sparse.close()
+
+
 # ---- row-sparse path == dense path, bit for bit --------------------------------------------------------
 @pytest.mark.parametrize("seed,variant,perceptual", [(0x5EED0000, 0, False), (0x5EED0001, 1, False), (0x5EED0007, 0, False),
                                                      (0x5EED0000, 0, True), (0x5EED0001, 1, True)])
