@@ -5,8 +5,24 @@ import glob
 import json
 import os
 import shutil
+import sys
 
 src = "gpurun_out/r2final"
+
+
+def copy_pmc():
+    for c in ("rgb", "perceptual", "dither", "images"):
+        p = os.path.join(src, "pmc_" + c, "pmc.json")
+        if os.path.exists(p):
+            d = json.load(open(p))
+            if c == "images":
+                d["calls"], d["candidates_per_call"] = 8, 128 * 64
+            json.dump(d, open(os.path.join("profiles", "r2_pmc_%s.json" % c), "w"), indent=1)
+
+
+if "--pmc-only" in sys.argv:  # r2_final.sh: the bench lines that follow take traffic and VALU counts from these summaries
+    copy_pmc()
+    sys.exit(0)
 
 
 def line(name):
@@ -17,13 +33,7 @@ for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(s
     shutil.copy(f, os.path.join("profiles", "r2_" + os.path.basename(f)))
 for f in glob.glob(os.path.join(src, "kernel_stats_*.txt")):
     shutil.copy(f, os.path.join("profiles", "r2_rocprofv3_" + os.path.basename(f)))
-for c in ("rgb", "perceptual", "dither", "images"):
-    p = os.path.join(src, "pmc_" + c, "pmc.json")
-    if os.path.exists(p):
-        d = json.load(open(p))
-        if c == "images":
-            d["calls"], d["candidates_per_call"] = 8, 128 * 64
-        json.dump(d, open(os.path.join("profiles", "r2_pmc_%s.json" % c), "w"), indent=1)
+copy_pmc()
 
 
 def M(v):

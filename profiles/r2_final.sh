@@ -3,10 +3,12 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/r2final; mkdir -p $O
+if [ -z "$R2_BENCH_ONLY" ]; then
 bash profiles/r2_pmc.sh r2final/pmc_rgb default 4096 > $O/pmc_rgb.log 2>&1
 bash profiles/r2_pmc.sh r2final/pmc_perceptual default 2048 --config perceptual > $O/pmc_perceptual.log 2>&1
 bash profiles/r2_pmc.sh r2final/pmc_dither default 2048 --config dither > $O/pmc_dither.log 2>&1
 bash profiles/r2_pmc.sh r2final/pmc_images 1 2048 --config images > $O/pmc_images.log 2>&1
+python profiles/r2_fill.py --pmc-only   # the bench lines below read traffic / VALU counts from profiles/r2_pmc_<config>.json
 echo pmc done
 stats() { # name, lanes, bench args
   n=$1; l=$2; shift 2
@@ -20,6 +22,7 @@ stats perceptual default --config perceptual
 stats dither default --config dither --steps 10 --warmup 2
 stats images default --config images --steps 20 --warmup 3
 echo stats done
+fi
 python bench.py > $O/bench_rgb.json 2> $O/bench_rgb.err
 python bench.py --config perceptual --steps 100 > $O/bench_perceptual.json 2> $O/bench_perceptual.err
 python bench.py --config dither --steps 40 > $O/bench_dither.json 2> $O/bench_dither.err
