@@ -567,7 +567,7 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     } else if (c->perceptual) {
         hipLaunchKernelGGL(k_candidate_lab, dim3((nc + 63) / 64), dim3(64), 0, stream, sp.cand_tab + 8 * (size_t)P.k0, (int)nc, c->d_lab_eotf, sp.cand_lab + 3 * (size_t)P.k0);
         HIPCHK(hipMemsetAsync(sp.bitmap + (size_t)P.k0 * (c->npx / 32), 0, sizeof(uint32_t) * (c->npx / 32) * nc, stream));
-        hipLaunchKernelGGL(k_sparse_scan_lab, dim3((nc + 3) / 4), dim3(256), 0, stream, P);
+        hipLaunchKernelGGL(k_sparse_scan_lab, dim3(nc), dim3(256), 0, stream, P);
     } else hipLaunchKernelGGL(k_sparse_scan, dim3((nc + 15) / 16), dim3(1024), 0, stream, P);
     hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P, 0);
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[1], stream));

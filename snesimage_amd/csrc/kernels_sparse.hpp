@@ -180,15 +180,22 @@ __device__ __forceinline__ void scan_publish(const SparseParams &P, const int k,
     }
 }
 
-// ---- perceptual scan: CIEDE2000 win test per contested pixel, one wave per candidate ------------------------
+// ---- perceptual scan: CIEDE2000 win test per contested pixel, one block (four waves) per candidate ---------------------
+// The evaluation is a long dependent chain (transcendentals): the kernel lives on resident waves.  One wave per candidate
+// leaves two waves per SIMD at 2,048 candidates per launch; the four waves of a block share a candidate instead, each
+// taking every fourth round of 64 contested pixels (won pixels go to the bitmap with atomics, the groups' leftmost won
+// columns to one LDS array; masks and counts are combined at the end).
 __device__ __forceinline__ void sparse_scan_lab_body(const SparseParams &P) {
     __shared__ uint32_t s_queue[4][128];
-    __shared__ int s_gx[4][64]; // per wave: smallest won x of every scale-0 group
+    __shared__ int s_gx[64]; // smallest won x of every scale-0 group
+    __shared__ unsigned long long s_mask[4];
+    __shared__ int s_xmin[4], s_won[4];
     const Geom &G = P.G;
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
-    s_gx[w][lane] = 0x7fff;
-    const int wi = (int)blockIdx.x * 4 + w;
+    if (w == 0) s_gx[lane] = 0x7fff;
+    __syncthreads();
+    const int wi = (int)blockIdx.x;
     const bool live = wi < P.ncand;
     const int k = P.k0 + (live ? wi : 0);
     unsigned long long mask = 0ull; int xmin = G.W, won = 0;
@@ -199,7 +206,7 @@ __device__ __forceinline__ void sparse_scan_lab_body(const SparseParams &P) {
         auto take = [&](uint32_t px) { // the candidate wins pixel px
             const int x = (int)(px & (unsigned)(G.W - 1)), y = (int)(px / (unsigned)G.W);
             atomicOr(&bm[px >> 5], 1u << (px & 31));
-            atomicMin(&s_gx[w][y >> 2], x);
+            atomicMin(&s_gx[y >> 2], x);
             mask |= 1ull << (y >> 2);
             xmin = min(xmin, x);
             won++;
@@ -215,12 +222,12 @@ __device__ __forceinline__ void sparse_scan_lab_body(const SparseParams &P) {
         // the few surviving lanes of every iteration.
         uint32_t *q = s_queue[w];
         int queued = 0; // wave-uniform
-        uint4 e_n = make_uint4(0, 0, 0, 0); float l_n = 0.0f; // entry and lightness of the NEXT round, fetched a round ahead
-        if (lane < n) { e_n = P.plist[lane]; l_n = P.labpx[3 * (size_t)e_n.x]; }
-        for (int i0 = 0; i0 < n; i0 += 64) {
+        uint4 e_n = make_uint4(0, 0, 0, 0); float l_n = 0.0f; // entry and lightness of the wave's NEXT round, fetched a round ahead
+        if (64 * w + lane < n) { e_n = P.plist[64 * w + lane]; l_n = P.labpx[3 * (size_t)e_n.x]; }
+        for (int i0 = 64 * w; i0 < n; i0 += 256) {
             const int i = i0 + lane;
             const uint4 e = e_n; const float tl = l_n;
-            if (i + 64 < n) { e_n = P.plist[i + 64]; l_n = P.labpx[3 * (size_t)e_n.x]; }
+            if (i + 256 < n) { e_n = P.plist[i + 256]; l_n = P.labpx[3 * (size_t)e_n.x]; }
             bool maybe = false;
             if (i < n) {
                 if (e.z == 0xffffffffu) take(e.x);
@@ -243,7 +250,12 @@ __device__ __forceinline__ void sparse_scan_lab_body(const SparseParams &P) {
             won += __shfl_xor(won, o);
         }
     }
-    scan_publish<4>(P, k, live, mask, xmin, won, s_gx[w][lane]);
+    if (lane == 0) { s_mask[w] = mask; s_xmin[w] = xmin; s_won[w] = won; }
+    __syncthreads();
+    mask = s_mask[0] | s_mask[1] | s_mask[2] | s_mask[3];
+    xmin = min(min(s_xmin[0], s_xmin[1]), min(s_xmin[2], s_xmin[3]));
+    won = s_won[0] + s_won[1] + s_won[2] + s_won[3];
+    scan_publish<4>(P, k, live && w == 0, mask, xmin, won, s_gx[lane]); // wave 0 publishes for the candidate
 }
 
 // ---- which groups does each candidate change? ---------------------------------------------------------
