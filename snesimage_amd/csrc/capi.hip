@@ -563,7 +563,7 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
         }
         if (c->sub_size == 15) hipLaunchKernelGGL((k_dither<false, 15, 2>), dim3(nc), dim3(128), 0, stream, Dp);
         else hipLaunchKernelGGL((k_dither<false, 0, 2>), dim3(nc), dim3(128), 0, stream, Dp);
-        hipLaunchKernelGGL(k_dither_diff, dim3((nc + 15) / 16), dim3(1024), 0, stream, P); // changed groups = where the maps differ
+        hipLaunchKernelGGL(k_dither_diff, dim3((nc + 3) / 4), dim3(1024), 0, stream, P); // changed groups = where the maps differ
     } else if (c->perceptual) {
         hipLaunchKernelGGL(k_candidate_lab, dim3((nc + 63) / 64), dim3(64), 0, stream, sp.cand_tab + 8 * (size_t)P.k0, (int)nc, c->d_lab_eotf, sp.cand_lab + 3 * (size_t)P.k0);
         HIPCHK(hipMemsetAsync(sp.bitmap + (size_t)P.k0 * (c->npx / 32), 0, sizeof(uint32_t) * (c->npx / 32) * nc, stream));

@@ -349,20 +349,24 @@ __device__ __forceinline__ void dither_first_body(const SparseParams &P) {
 // The error a changed pixel injects is diffused with a total weight of 0.8 per row, so it fades: away from the pixels the
 // candidate takes, its resumed run soon chooses what B chose.  The score depends on the picture only, so the changed set
 // of the group-sparse scorer is simply where the two palette_maps differ (a pixel on the slot's index always does: B never
-// uses it).  One wave per candidate, one row per iteration (lane = four pixels); publishes like the scans.
+// uses it).  Four waves per candidate (a block = four candidates), each taking every fourth chunk of eight rows (lane = four
+// pixels; the loop is a chain of loads, and one wave per candidate left two waves per SIMD); publishes like the scans.
 __device__ __forceinline__ void dither_diff_body(const SparseParams &P) {
-    __shared__ int s_gx[16][64];
+    __shared__ int s_gx[4][64];
+    __shared__ unsigned long long s_mask[16];
+    __shared__ int s_xmin[16], s_won[16];
     const Geom &G = P.G;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int wi = (int)blockIdx.x * 16 + w;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = w >> 2, q = w & 3;
+    const int wi = (int)blockIdx.x * 4 + c;
     const bool live = wi < P.ncand;
     const int k = P.k0 + (live ? wi : 0);
-    s_gx[w][lane] = 0x7fff;
+    if (q == 0) s_gx[c][lane] = 0x7fff;
+    __syncthreads();
     unsigned long long mask = 0ull; int xmin = G.W, won = 0;
     if (live) {
         const uint32_t *mc = reinterpret_cast<const uint32_t *>(P.maps + (size_t)(k - P.k0) * G.W * G.H), *mb = reinterpret_cast<const uint32_t *>(P.bmap);
         const int y0 = min(4 * P.first[k], G.H);
-        for (int yb = y0; yb < G.H; yb += 8) { // W = 256: 64 words per row; two groups' rows in flight (the loop is a chain of loads)
+        for (int yb = y0 + 8 * q; yb < G.H; yb += 32) { // W = 256: 64 words per row; a chunk = two whole groups, one wave's alone
             uint32_t dd[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) { const int yy = min(yb + u, G.H - 1); dd[u] = mc[yy * 64 + lane] ^ mb[yy * 64 + lane]; } // (rows past the image are clamped here and dropped below)
@@ -375,7 +379,7 @@ __device__ __forceinline__ void dither_diff_body(const SparseParams &P) {
                     const int l0 = __ffsll((long long)m) - 1;
                     const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, l0);
                     const int x = 4 * l0 + ((__ffs((int)d0) - 1) >> 3);
-                    if (lane == 0) s_gx[w][y >> 2] = min(s_gx[w][y >> 2], x);
+                    if (lane == 0) s_gx[c][y >> 2] = min(s_gx[c][y >> 2], x);
                     mask |= 1ull << (y >> 2);
                     xmin = min(xmin, x);
                     won += __popcll(m); // (words, not pixels: only a statistic)
@@ -383,7 +387,12 @@ __device__ __forceinline__ void dither_diff_body(const SparseParams &P) {
             }
         }
     }
-    scan_publish<16>(P, k, live, mask, xmin, won, s_gx[w][lane]);
+    if (lane == 0) { s_mask[w] = mask; s_xmin[w] = xmin; s_won[w] = won; }
+    __syncthreads();
+    mask = s_mask[4 * c] | s_mask[4 * c + 1] | s_mask[4 * c + 2] | s_mask[4 * c + 3];
+    xmin = min(min(s_xmin[4 * c], s_xmin[4 * c + 1]), min(s_xmin[4 * c + 2], s_xmin[4 * c + 3]));
+    won = s_won[4 * c] + s_won[4 * c + 1] + s_won[4 * c + 2] + s_won[4 * c + 3];
+    scan_publish<16>(P, k, live && q == 0, mask, xmin, won, s_gx[c][lane]); // the candidate's first wave publishes
 }
 
 // ---- downscale chain + XYB on changed groups only -------------------------------------------------------
