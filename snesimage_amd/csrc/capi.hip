@@ -145,7 +145,7 @@ struct snesimage_ctx {
         float *store = nullptr, *cand_tab = nullptr, *cand_lab = nullptr, *ckf = nullptr, *ckh = nullptr; long long zeros_off = 0; uint32_t *bitmap = nullptr; double *cka = nullptr, *part = nullptr;
         CandMeta *meta = nullptr; unsigned int *items = nullptr; int *item_count = nullptr; long long item_stride = 0; int *order = nullptr, *first = nullptr;
         uint4 *plist = nullptr; int *plist_count = nullptr; bool plist_valid = false;
-        hipStream_t base_stream = nullptr; hipEvent_t ev_base_in = nullptr, ev_base_h = nullptr, ev_base_done = nullptr; // B's H and V passes run beside the candidates' scan/down/H
+        hipStream_t base_stream = nullptr; hipEvent_t ev_base_in = nullptr, ev_base_h = nullptr, ev_base_done = nullptr, ev_base_narrow = nullptr; // B's H and V passes run beside the candidates' scan/down/H
         // --dither (RGB distance): B dithered once per slot (k_dither MODE 1) and the candidates resumed from its checkpoints (MODE 2)
         uint8_t *dmaps = nullptr, *dmapsC4 = nullptr; // [lane][cap][W*H] candidates' palette_maps, row-major and C4
         uint8_t *bmap = nullptr, *bmapC4 = nullptr, *bcand = nullptr; unsigned long long *dpack = nullptr; double *ckd = nullptr; uint32_t slot_ci = 0;
@@ -455,6 +455,7 @@ int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
         HIPCHK(hipStreamCreateWithPriority(&sp.base_stream, hipStreamNonBlocking, prio_hi));
         HIPCHK(hipEventCreateWithFlags(&sp.ev_base_in, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sp.ev_base_h, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&sp.ev_base_narrow, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sp.ev_base_done, hipEventDisableTiming));
     }
     HIPCHK(dmalloc(&sp.item_count, sizeof(int) * (kItemLists * (c->nlanes + 1) + 1))); // + the contested-pixel count, right behind B's counters
@@ -533,11 +534,14 @@ int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si) {
         // wide scales: B rows start at column 0 (list s*kColBuckets) and leave the per-block H checkpoints and the scale-0 XYB plane
         hipLaunchKernelGGL(k_sparse_h2, dim3((unsigned)((G.sh[0] / 4 * 3 + 15) / 16), (unsigned)(P.s_first * kColBuckets)), dim3(64), 0, bs, P);
         if (sp.side) HIPCHK(hipEventRecord(sp.ev_base_h, bs)); // the candidates' H pass resumes from the block checkpoints this launch leaves
+        // the wide scales' V sweep first: the candidates' V pass (the bulk of a call) waits for it alone; the narrow scales'
+        // sweeps follow and are awaited by the candidates' narrow V pass at the very end of the launch group
+        if (P.s_first > 0) hipLaunchKernelGGL(k_sparse_v2_base, dim3(3, (unsigned)P.s_first), dim3(256), 0, bs, P);
+        if (sp.side) HIPCHK(hipEventRecord(sp.ev_base_done, bs));
         if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((G.sh[P.s_first] / 4 * 3 + 15) / 16), (unsigned)((G.nscales - P.s_first) * kColBuckets)), dim3(64), 0, bs, P);
         if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_v_base_narrow, dim3(3, (unsigned)(G.nscales - P.s_first)), dim3(256), 0, bs, P);
-        if (P.s_first > 0) hipLaunchKernelGGL(k_sparse_v2_base, dim3(3, (unsigned)P.s_first), dim3(256), 0, bs, P);
         HIPCHK(hipGetLastError());
-        if (sp.side) HIPCHK(hipEventRecord(sp.ev_base_done, bs));
+        if (sp.side) HIPCHK(hipEventRecord(sp.ev_base_narrow, bs));
         sp.plist_valid = true;
     }
     return SNES_OK;
@@ -577,10 +581,13 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
       if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((gx + 7) / 8), (unsigned)((G.nscales - P.s_first) * kColBuckets)), dim3(64), 0, stream, P); }
     if (sp.side || stream != c->stream) HIPCHK(hipStreamWaitEvent(stream, sp.side ? sp.ev_base_done : c->ev_ready, 0)); // checkpoints and H output of B
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[2], stream));
-    if (c->sp.lpt) { hipLaunchKernelGGL(k_sparse_order, dim3(1), dim3(1024), 0, stream, P, sp.order + P.k0); P.order = sp.order + P.k0; }
+    if (c->sp.lpt && nc > 512) { // (a short list's blocks are all resident at once: their order is immaterial)
+        hipLaunchKernelGGL(k_sparse_order, dim3(1), dim3(1024), 0, stream, P, sp.order + P.k0); P.order = sp.order + P.k0;
+    }
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[3], stream));
     hipLaunchKernelGGL(k_sparse_v2, dim3(nc * 3, (unsigned)P.s_first), dim3(256), 0, stream, P);
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[4], stream)); // ev[3]..ev[4]: k_sparse_v2 alone
+    if (sp.side) HIPCHK(hipStreamWaitEvent(stream, sp.ev_base_narrow, 0)); // B's narrow-scale sweeps
     if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_v, dim3((nc * 3 + 7) / 8, (unsigned)(G.nscales - P.s_first)), dim3(256), 0, stream, P); // narrow scales: >= 8 pairs per block
     hipLaunchKernelGGL(k_final_score, dim3((nc + 63) / 64), dim3(64), 0, stream, sp.part + (size_t)P.k0 * G.nscales * 18, (int)nc, G, d_errors, err_stride, err_offset, P.item_count, (int)kItemLists);
     if (c->dither) { // the lane remembers the map of its best candidate so far: the commit adopts the winner's instead of dithering again
@@ -902,7 +909,7 @@ void snesimage_destroy(snesimage_ctx *c) {
     dfree(c->d_cand); dfree(c->d_cand_sel); dfree(c->d_errs); dfree(c->d_errs_sel); dfree(c->d_inc_err); dfree(c->d_last); dfree(c->d_scratch_err); dfree(c->d_dummy_cand);
     for (auto &L : c->extra) { if (L.stream) (void)hipStreamSynchronize(L.stream); dfree(L.d_mapsC4); dfree(L.d_mapsR4); dfree(L.d_work); dfree(L.d_cand_tab); dfree(L.d_cand_lab); dfree(L.d_part); dfree(L.d_maps); dfree(L.d_mapsT); if (L.done) (void)hipEventDestroy(L.done); if (L.stream) (void)hipStreamDestroy(L.stream); }
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
-    { auto &q = c->sp; if (q.base_stream) { (void)hipStreamSynchronize(q.base_stream); (void)hipStreamDestroy(q.base_stream); (void)hipEventDestroy(q.ev_base_in); (void)hipEventDestroy(q.ev_base_h); (void)hipEventDestroy(q.ev_base_done); } dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.order); dfree(q.first); dfree(q.cand_lab); dfree(q.bitmap); dfree(q.ckh);
+    { auto &q = c->sp; if (q.base_stream) { (void)hipStreamSynchronize(q.base_stream); (void)hipStreamDestroy(q.base_stream); (void)hipEventDestroy(q.ev_base_in); (void)hipEventDestroy(q.ev_base_h); (void)hipEventDestroy(q.ev_base_narrow); (void)hipEventDestroy(q.ev_base_done); } dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.order); dfree(q.first); dfree(q.cand_lab); dfree(q.bitmap); dfree(q.ckh);
       dfree(q.dmaps); dfree(q.dmapsC4); dfree(q.bmap); dfree(q.bmapC4); dfree(q.bcand); dfree(q.dpack); dfree(q.ckd); }
     kmeans_free(c->km);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
