@@ -240,7 +240,10 @@ __device__ __forceinline__ void sparse_v2_body(const SparseParams &P, const int 
     const int pair_raw = bx * ppw + ql;
     const bool active = pair_raw < npairs;
     const int pair = active ? pair_raw : 0;
-    const int k = BASE ? P.base : uni(P.k0 + (P.order ? P.order[pair / 3] : pair / 3)), ch = pair % 3;
+    // pairs are taken channel by channel: what the waves of a channel share (B's planes and the source's, ~2.4 MB at scale 0)
+    // then fits an XCD's L2, which the three channels' together do not
+    const int ch = BASE ? pair : pair / P.ncand, ci = BASE ? 0 : pair - ch * P.ncand;
+    const int k = BASE ? P.base : uni(P.k0 + (P.order ? P.order[ci] : ci));
     const CandMeta *M = P.meta + k;
     // Effective slot of every group for this wave: the candidate's own rows only where its H pass has written this wave's
     // columns (a group whose first changed block lies to the right leaves these columns as B has them).  The wave resumes
