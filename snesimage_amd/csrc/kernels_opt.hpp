@@ -142,13 +142,17 @@ __global__ __launch_bounds__(NT) void k_dither(DitherParams P) {
         if (mapC4) for (int i = j; i < y0 * (W >> 2); i += NT) { const int q = i / y0, yy = i - q * y0; mapC4[q * H + yy] = bC4[q * H + yy]; }
         if (y0 >= H) return;
     }
-    // MODE 2: the row above the first row is B's: its state (the checkpoint of the group) reaches thread 0 through a
-    // three-column register window refilled one step ahead — 6 KB of LDS less per block than staging the row, i.e. half as
-    // many blocks again per CU for a kernel that lives on occupancy
-    const bool ck_row = MODE == 2 && j == 0 && y0 > 0;
+    // MODE 2: the row above the first row is B's.  Its state (the checkpoint of the group) reaches thread 0 the way any row
+    // above does, through the ring of the thread "above" it — the block's last thread, whose own rows start 2 (NT - 1) = 254
+    // steps in: until then it plays row y0 - 1, two columns ahead of thread 0 like every upper row, writing B's checkpoint
+    // instead of dithering.  No special case in the step, nothing extra in registers.
+    const bool ck_feed = MODE == 2 && j == NT - 1 && y0 > 0;
     const double *ckp = MODE == 2 ? P.ck_in + (size_t)(y0 >> 2) * W * 3 : nullptr;
-    double ckw[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}}; // columns x-1, x, x+1
-    if (ck_row) { for (int c = 0; c < 3; c++) { ckw[1][c] = ckp[c]; ckw[2][c] = ckp[3 + c]; } }
+    double ck_n[3] = {0.0, 0.0, 0.0}; // column t + 2 of the checkpoint, fetched a step ahead
+    if (ck_feed) {
+        for (int c = 0; c < 3; c++) { ring[j][0][c] = ckp[c]; ring[j][1][c] = ckp[3 + c]; ck_n[c] = ckp[6 + c]; }
+    }
+    __syncthreads();
     const int nrows = H - y0;
     const int rows_per_thread = (nrows + NT - 1) / NT; // at most H / NT
     const int nth = nrows < NT ? nrows : NT;
@@ -171,11 +175,6 @@ __global__ __launch_bounds__(NT) void k_dither(DitherParams P) {
             double r0[3], r1[3], r2[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) { r0[c] = ru0[c]; r1[c] = ru1[c]; r2[c] = ru2[c]; }
-            if (MODE == 2 && ck_row && y == y0) { // the row above is B's
-#pragma unroll
-                for (int c = 0; c < 3; c++) { r0[c] = ckw[0][c]; r1[c] = ckw[1][c]; r2[c] = ckw[2][c]; ckw[0][c] = ckw[1][c]; ckw[1][c] = ckw[2][c]; }
-                if (x + 2 < W) { for (int c = 0; c < 3; c++) ckw[2][c] = ckp[3 * (x + 2) + c]; }
-            }
             if ((x & 3) == 0) { // this thread's stream continues with (x+4, y), then row y+128
                 o_cur = o_nxt;
                 const int ln = local + 4;
@@ -264,6 +263,11 @@ __global__ __launch_bounds__(NT) void k_dither(DitherParams P) {
             // (x-1), x, (x+1) & 3 — never the same slot, so one barrier per step orders everything.
             ring[j][x & 3][0] = v[0]; ring[j][x & 3][1] = v[1]; ring[j][x & 3][2] = v[2];
             if (MODE == 1 && (y & 3) == 3 && y + 1 < H) { double *co = P.ck_out + ((size_t)((y + 1) >> 2) * W + x) * 3; co[0] = v[0]; co[1] = v[1]; co[2] = v[2]; }
+        }
+        if (MODE == 2 && ck_feed && t + 2 < W) { // row y0 - 1, column t + 2 (this thread's own stream starts at step 2 (NT - 1) = W - 2)
+            const int xc = t + 2;
+            ring[j][xc & 3][0] = ck_n[0]; ring[j][xc & 3][1] = ck_n[1]; ring[j][xc & 3][2] = ck_n[2];
+            if (xc + 1 < W) { ck_n[0] = ckp[3 * (xc + 1)]; ck_n[1] = ckp[3 * (xc + 1) + 1]; ck_n[2] = ckp[3 * (xc + 1) + 2]; }
         }
         __syncthreads();
     }
