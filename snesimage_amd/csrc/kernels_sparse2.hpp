@@ -56,7 +56,8 @@ struct H2Shared {
     __attribute__((aligned(16))) float out[16 * (4 * 32 + 4)];  // staging: per item [plane][8 columns][4 rows] + pad
     long long hbase[16], xbase[16];                             // per item: float offset of its H output / XYB planes inside P.store, -1 = no item
 };
-template <bool S0>
+// BASE: the launch is B's own H pass (every item is B's: no win test, and the block checkpoints are written) / the candidates'
+template <bool S0, bool BASE>
 __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int list, const int bx, const int gx, H2Shared &sh) {
     constexpr int NP = S0 ? 4 : 3;        // staged planes: the three H outputs (+ the XYB input at scale 0)
     constexpr int PW = 32;                // staged floats per plane: 8 columns x 4 rows = one 128-byte line of the XT4 / R4 layouts
@@ -82,7 +83,7 @@ __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int 
         const bool valid = qi < count;
         const unsigned int it = P.items[(size_t)list * P.item_stride + (valid ? qi : i0)];
         const int k = (int)(it >> 8), j = (int)((it >> 2) & 63u), ch = (int)(it & 3u);
-        const bool is_base = (k == P.base);
+        constexpr bool is_base = BASE;
         const CandMeta *M = P.meta + k;
         const int y = 4 * (int)M->glist[P.S.goff[s] + j] + r;
         const size_t ns = (size_t)W * H;
@@ -150,7 +151,7 @@ __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int 
                     r2[u].z = c2 == (uint32_t)P.ncol ? cand_v : lut[c2]; r2[u].w = c3 == (uint32_t)P.ncol ? cand_v : lut[c3];
                 }
                 if (g < gs) continue; // warm-up: the ring fills, the state is B's checkpoint
-                if (P.is_base && g > 0 && (g & 15) == 0 && g < G4 && valid) { // B: the state on entering block g/16
+                if (BASE && g > 0 && (g & 15) == 0 && g < G4 && valid) { // B: the state on entering block g/16
                     float *co = P.ckh + P.S.off_ckh[s] + ((size_t)(ch * 3 + (g >> 4) - 1) * 18) * H + y;
 #pragma unroll
                     for (int p = 0; p < 3; p++)
@@ -407,13 +408,15 @@ __device__ __forceinline__ void sparse_v2_body(const SparseParams &P, const int 
 #undef SNES_VSTEP
 
 // entry points: the H pass takes the lists of the wide scales (grid.y = list), the V pass the wide scales (grid.y = scale)
+template <bool BASE>
 __device__ __forceinline__ void sparse_h2_dispatch(const SparseParams &P, const int list, const int bx, const int gx) {
     const int s = list / kColBuckets;
     if (s >= P.G.nscales || P.G.sw[s] < 64 || (list % kColBuckets) >= (P.G.sw[s] >> 6)) return;
     __shared__ H2Shared sh;
-    if (s == 0) sparse_h2_body<true>(P, list, bx, gx, sh); else sparse_h2_body<false>(P, list, bx, gx, sh);
+    if (s == 0) sparse_h2_body<true, BASE>(P, list, bx, gx, sh); else sparse_h2_body<false, BASE>(P, list, bx, gx, sh);
 }
-__global__ __launch_bounds__(64) void k_sparse_h2(SparseParams P) { sparse_h2_dispatch(P, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x); }
+__global__ __launch_bounds__(64) void k_sparse_h2(SparseParams P) { sparse_h2_dispatch<false>(P, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x); }
+__global__ __launch_bounds__(64) void k_sparse_h2_base(SparseParams P) { sparse_h2_dispatch<true>(P, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x); }
 __global__ __launch_bounds__(256, 5) void k_sparse_v2(SparseParams P) { if ((int)blockIdx.y < P.G.nscales && P.G.sw[blockIdx.y] >= 64) sparse_v2_body<false>(P, (int)blockIdx.y, (int)blockIdx.x); }
 // B: the wide scales in this body (grid.y = scale), the narrow ones in the general one (grid.y = scale - s_first), two launches:
 // one kernel holding both bodies would take the larger register allocation for every block
