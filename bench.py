@@ -28,6 +28,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_CANDIDATE = 263408  # 262,144 source RGBA8 + 1,024 tile map + 240 palette
+# SURVEY §8(d)'s secondary figure: the bytes of a DENSE SSIMULACRA2 evaluation per candidate (every plane of every scale
+# written and read once).  Quoted beside the primary one; the group-sparse path does not move them (a fraction above 1 of
+# peak says just that: the dense evaluation's traffic is avoided, not streamed faster than the memory can).
+SSIM2_DENSE_BYTES_PER_CANDIDATE = 3408368
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0  # G wave64 instructions/s: 1,024 SIMD-32s, 2 cycles per binary32 wave instruction, 2.4 GHz
 
@@ -351,7 +355,8 @@ def main():
                          "algorithmic_bytes_per_candidate": ALGO_BYTES_PER_CANDIDATE, "candidates_per_launch": per_launch,
                          "avg_launch_ms": dom_ms, "group_ms": tim["group_ms"] / max(1, tim["launches"]),
                          "pipeline_achieved": value / world * ALGO_BYTES_PER_CANDIDATE / 1e9,
-                         "pipeline_frac": value / world * ALGO_BYTES_PER_CANDIDATE / 1e9 / HBM_PEAK_GBS},
+                         "pipeline_frac": value / world * ALGO_BYTES_PER_CANDIDATE / 1e9 / HBM_PEAK_GBS,
+                         "pipeline_frac_dense_ssimulacra2_bytes": value / world * SSIM2_DENSE_BYTES_PER_CANDIDATE / 1e9 / HBM_PEAK_GBS},
         }
         out["valu_roofline"] = valu
         out.update(extras)
