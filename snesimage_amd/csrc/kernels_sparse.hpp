@@ -463,7 +463,7 @@ __device__ __forceinline__ void sparse_down_body(const SparseParams &P, int only
             for (int c = 0; c < 3; c++) {
                 ol[(size_t)c * 4 * Ws + (size_t)(x >> 2) * 16 + r * 4 + (x & 3)] = v[c];
                 oc[(size_t)c * 4 * Ws + (size_t)(x >> 2) * 16 + r * 4 + (x & 3)] = xyb[c];
-                orr[(size_t)c * 4 * Ws + (size_t)x * 4 + r] = xyb[c];
+                if (is_base || Ws < 64) orr[(size_t)c * 4 * Ws + (size_t)x * 4 + r] = xyb[c]; // (wide scales: the candidates' H pass writes the R4 copy)
             }
         }
         __syncthreads(); // the rows written above are read by this block at the next scale

@@ -59,7 +59,10 @@ struct H2Shared {
 // BASE: the launch is B's own H pass (every item is B's: no win test, and the block checkpoints are written) / the candidates'
 template <bool S0, bool BASE>
 __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int list, const int bx, const int gx, H2Shared &sh) {
-    constexpr int NP = S0 ? 4 : 3;        // staged planes: the three H outputs (+ the XYB input at scale 0)
+    // staged planes: the three H outputs + the XYB input, which the V pass reads in the R4 layout (at scale 0 it is looked up
+    // here; at the other scales it is the downscale's output in the C4 layout, and rewriting it from here — whole lines,
+    // only from the row's first block on — is cheaper than a second scattered copy from the downscale; B's are written there)
+    constexpr int NP = (S0 || !BASE) ? 4 : 3;
     constexpr int PW = 32;                // staged floats per plane: 8 columns x 4 rows = one 128-byte line of the XT4 / R4 layouts
     constexpr int ISTR = NP * PW + 4;     // staging words per item; the pad spreads the quads' rows over the LDS banks
     float *const s_lut = sh.lut, *const s_out = sh.out;
@@ -173,19 +176,19 @@ __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int 
                     float *so = s_out + (lane >> 2) * ISTR + (((g - 1) & 1) << 4) + r;
 #pragma unroll
                     for (int p = 0; p < 3; p++) { so[p * PW + 0] = outp[p][0]; so[p * PW + 4] = outp[p][1]; so[p * PW + 8] = outp[p][2]; so[p * PW + 12] = outp[p][3]; }
-                    if (S0) { so[3 * PW + 0] = r2[ul].x; so[3 * PW + 4] = r2[ul].y; so[3 * PW + 8] = r2[ul].z; so[3 * PW + 12] = r2[ul].w; }
+                    if (NP == 4) { so[3 * PW + 0] = r2[ul].x; so[3 * PW + 4] = r2[ul].y; so[3 * PW + 8] = r2[ul].z; so[3 * PW + 12] = r2[ul].w; }
                     if ((g & 1) == 0) { // 8 columns complete (gs and W/4 are even): one store instruction per two items = their NP planes as 128-byte lines
                         __syncthreads();
                         const int x0 = (g - 2) << 2; // first column of the run
                         const int half = lane >> 5, l = lane & 31, p = l >> 3, c = l & 7;
                         // float offset of this lane's 16 bytes behind the item's base: plane p of the H output (XT4 block of x0), or the XYB plane (R4)
-                        const uint32_t o_l = (S0 && p == 3) ? (uint32_t)(x0 << 2) + (uint32_t)(c << 2) : (uint32_t)p * 4u * (uint32_t)W + (uint32_t)((x0 >> 6) << 8) + (uint32_t)((x0 & 63) << 2) + (uint32_t)(c << 2);
+                        const uint32_t o_l = (NP == 4 && p == 3) ? (uint32_t)(x0 << 2) + (uint32_t)(c << 2) : (uint32_t)p * 4u * (uint32_t)W + (uint32_t)((x0 >> 6) << 8) + (uint32_t)((x0 & 63) << 2) + (uint32_t)(c << 2);
 #pragma unroll 4
                         for (int m = 0; m < 16; m += 2) {
                             const long long hb = s_hbase[m + half];
                             if (hb >= 0 && l < NP * 8) {
                                 const float4 v = *reinterpret_cast<const float4 *>(s_out + (m + half) * ISTR + l * 4);
-                                float *dst = P.store + ((S0 && p == 3) ? s_xbase[m + half] : hb) + o_l;
+                                float *dst = P.store + ((NP == 4 && p == 3) ? s_xbase[m + half] : hb) + o_l;
                                 *reinterpret_cast<float4 *>(dst) = v;
                             }
                         }
