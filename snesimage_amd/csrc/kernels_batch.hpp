@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256, 5) void kb_sparse_v2(const BatchArgs *__restri
 __global__ __launch_bounds__(256) void kb_sparse_v_base(const BatchArgs *__restrict__ A) { SNES_BATCH_XCD; if (bb.y < a.Pb.G.nscales && a.Pb.G.sw[bb.y] >= 64) sparse_v2_body<true>(a.Pb, bb.y, bb.x); }
 __global__ __launch_bounds__(256, 1) void kb_sparse_v_base_narrow(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; sparse_v_base_narrow_dispatch(a.Pb); }
 __global__ __launch_bounds__(1024) void kb_sparse_order(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; sparse_order_body(a.Pc, const_cast<int *>(a.Pc.order)); }
-__global__ __launch_bounds__(256, 4) void kb_sparse_v(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; sparse_v_body<false, 2, 2>(a.Pc, (int)blockIdx.y + a.Pc.s_first); }
+__global__ __launch_bounds__(256, 2) void kb_sparse_v(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; sparse_v_body<false, 2, 2>(a.Pc, (int)blockIdx.y + a.Pc.s_first); }
 __global__ void kb_final_score(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; final_score_body(a.part, a.n, a.Pc.G, a.errors, 1, 0, a.Pc.item_count, (int)kItemLists); }
 __global__ __launch_bounds__(256) void kb_commit(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; commit_body(a.errors, a.n, a.cand, a.colors, a.slot, a.nes, a.inc_err, a.last, a.T); }
 #undef SNES_BATCH_IMG

@@ -907,7 +907,7 @@ __device__ __forceinline__ void sparse_v_body(const SparseParams &P, const int s
     }
 }
 // candidates: every scale in one launch, flags decided at run time (see sparse_v_body)
-__global__ __launch_bounds__(256, 4) void k_sparse_v(SparseParams P) { sparse_v_body<false, 2, 2>(P, (int)blockIdx.y + P.s_first); } // grid.y = narrow scales
+__global__ __launch_bounds__(256, 2) void k_sparse_v(SparseParams P) { sparse_v_body<false, 2, 2>(P, (int)blockIdx.y + P.s_first); } // grid.y = narrow scales
 // B: one launch as well, each scale in its specialised flavour
 __device__ __forceinline__ void sparse_v_base_body(const SparseParams &P) {
     const int s = (int)blockIdx.y;
