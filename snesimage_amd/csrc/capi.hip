@@ -496,6 +496,8 @@ SparseParams sparse_params(snesimage_ctx *c, uint32_t lane) {
     return P;
 }
 
+static size_t h2_lds(const snesimage_ctx *c) { return sizeof(float) * 3 * (size_t)(c->ncol + 2); } // k_sparse_h2's palette table in LDS
+
 // B of the current slot: compact list of contested pixels, then the pipeline once with checkpoints (main stream)
 int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si) {
     auto &sp = c->sp;
@@ -532,7 +534,7 @@ int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si) {
         if (sp.side) { HIPCHK(hipEventRecord(sp.ev_base_in, c->stream)); HIPCHK(hipStreamWaitEvent(bs, sp.ev_base_in, 0)); }
         hipLaunchKernelGGL(k_sparse_scan, dim3(1), dim3(1024), 0, bs, P); // B's work items (every group, from column 0): only B's own sweeps read them
         // wide scales: B rows start at column 0 (list s*kColBuckets) and leave the per-block H checkpoints and the scale-0 XYB plane
-        hipLaunchKernelGGL(k_sparse_h2_base, dim3((unsigned)((G.sh[0] / 4 * 3 + 15) / 16), (unsigned)(P.s_first * kColBuckets)), dim3(64), 0, bs, P);
+        hipLaunchKernelGGL(k_sparse_h2_base, dim3((unsigned)((G.sh[0] / 4 * 3 + 15) / 16), (unsigned)(P.s_first * kColBuckets)), dim3(64), h2_lds(c), bs, P);
         if (sp.side) HIPCHK(hipEventRecord(sp.ev_base_h, bs)); // the candidates' H pass resumes from the block checkpoints this launch leaves
         // the wide scales' V sweep first: the candidates' V pass (the bulk of a call) waits for it alone; the narrow scales'
         // sweeps follow and are awaited by the candidates' narrow V pass at the very end of the launch group
@@ -577,7 +579,7 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[1], stream));
     if (sp.side) HIPCHK(hipStreamWaitEvent(stream, sp.ev_base_h, 0)); // B's H-pass checkpoints (a short list gets here before B's sweep is through)
     { size_t gx = ((size_t)nc * (G.sh[0] / 4) * 3 + 15) / 16; if (gx > sp.hgrid) gx = sp.hgrid; // grid-stride over the item quads
-      hipLaunchKernelGGL(k_sparse_h2, dim3((unsigned)gx, (unsigned)(P.s_first * kColBuckets)), dim3(64), 0, stream, P);
+      hipLaunchKernelGGL(k_sparse_h2, dim3((unsigned)gx, (unsigned)(P.s_first * kColBuckets)), dim3(64), h2_lds(c), stream, P);
       if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((gx + 7) / 8), (unsigned)((G.nscales - P.s_first) * kColBuckets)), dim3(64), 0, stream, P); }
     if (sp.side || stream != c->stream) HIPCHK(hipStreamWaitEvent(stream, sp.side ? sp.ev_base_done : c->ev_ready, 0)); // checkpoints and H output of B
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[2], stream));

@@ -52,7 +52,6 @@ namespace snes {
 // LDS of one block (= one wave), shared by the two instantiations of the body (a block runs one of them; declared inside the
 // template each instantiation would take its own copy and the kernel would hold both: 32 KB per wave, five waves per CU)
 struct H2Shared {
-    float lut[3 * 256];                                         // scale 0: XYB of the palette entries
     __attribute__((aligned(16))) float out[16 * (4 * 32 + 4)];  // staging: per item [plane][8 columns][4 rows] + pad
     long long hbase[16], xbase[16];                             // per item: float offset of its H output / XYB planes inside P.store, -1 = no item
 };
@@ -65,7 +64,9 @@ __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int 
     constexpr int NP = (S0 || !BASE) ? 4 : 3;
     constexpr int PW = 32;                // staged floats per plane: 8 columns x 4 rows = one 128-byte line of the XT4 / R4 layouts
     constexpr int ISTR = NP * PW + 4;     // staging words per item; the pad spreads the quads' rows over the LDS banks
-    float *const s_lut = sh.lut, *const s_out = sh.out;
+    extern __shared__ float s_lut[]; // scale 0: XYB of the ncol + 2 colour indices, three planes (dynamic: 12 (ncol + 2) bytes — the waves a CU holds are what this kernel lives on)
+    const int lstr = P.ncol + 2;
+    float *const s_out = sh.out;
     long long *const s_hbase = sh.hbase, *const s_xbase = sh.xbase;
     const Geom &G = P.G;
     const int s = list / kColBuckets, cb = list % kColBuckets;
@@ -74,7 +75,7 @@ __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int 
     const int count = P.item_count[list];
     if (bx * 16 >= count) return;
     if (S0) {
-        for (int i = lane; i < 3 * 256; i += 64) { const int c = i >> 8, j = i & 255; s_lut[i] = (j < P.ncol + 2) ? P.pal_xyb[3 * j + c] : 0.0f; }
+        for (int i = lane; i < 3 * lstr; i += 64) { const int c = i / lstr, j = i - c * lstr; s_lut[i] = P.pal_xyb[3 * j + c]; }
         __syncthreads();
     }
     const float n2_0 = P.K.n2[0], n2_1 = P.K.n2[1], n2_2 = P.K.n2[2];
@@ -149,7 +150,7 @@ __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int 
                         c0 = sparse_ci(c_pa.x, c_pa.y & never, crgb, (uint32_t)P.ncol); c1 = sparse_ci(c_pa.z, c_pa.w & never, crgb, (uint32_t)P.ncol);
                         c2 = sparse_ci(c_pb.x, c_pb.y & never, crgb, (uint32_t)P.ncol); c3 = sparse_ci(c_pb.z, c_pb.w & never, crgb, (uint32_t)P.ncol);
                     }
-                    const float *lut = s_lut + (ch << 8);
+                    const float *lut = s_lut + ch * lstr;
                     r2[u].x = c0 == (uint32_t)P.ncol ? cand_v : lut[c0]; r2[u].y = c1 == (uint32_t)P.ncol ? cand_v : lut[c1];
                     r2[u].z = c2 == (uint32_t)P.ncol ? cand_v : lut[c2]; r2[u].w = c3 == (uint32_t)P.ncol ? cand_v : lut[c3];
                 }
