@@ -463,9 +463,15 @@ __global__ void k_debug_math(int op, const float *__restrict__ x, const float *_
 struct KmeansWork {
     double *pts = nullptr; uint32_t *assign = nullptr; double *centres = nullptr; int *rounds = nullptr;
     size_t cap_pts = 0; int cap_prob = 0, cap_k = 0;
+    // small scratch the initialisers need on every call, kept with the context: hipMalloc / hipFree per call synchronise the
+    // whole device, which serialises the host threads that initialise the images of a throughput batch side by side
+    int *d_n = nullptr; long long *d_off = nullptr; float *d_sums = nullptr; int *d_counts = nullptr; uint32_t *d_index = nullptr;
+    int cap_meta = 0, cap_tile = 0; size_t cap_index = 0;
 };
 inline void kmeans_free(KmeansWork &w) {
     if (w.pts) (void)hipFree(w.pts); if (w.assign) (void)hipFree(w.assign); if (w.centres) (void)hipFree(w.centres); if (w.rounds) (void)hipFree(w.rounds);
+    if (w.d_n) (void)hipFree(w.d_n); if (w.d_off) (void)hipFree(w.d_off); if (w.d_sums) (void)hipFree(w.d_sums); if (w.d_counts) (void)hipFree(w.d_counts);
+    if (w.d_index) (void)hipFree(w.d_index);
     w = KmeansWork{};
 }
 
