@@ -273,6 +273,157 @@ __global__ __launch_bounds__(NT) void k_dither(DitherParams P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_dither with a quad of lanes per row (RGB distance only).  The step of k_dither is one dependent chain of ~270
+// instructions per row — three channels' diffused error and target one after the other, then a 15-entry search — and both
+// the base image's run (766 steps of a single block) and the resumed runs are bound by its length.  Here lane q < 3 of a
+// quad carries channel q (its ring column, its diffusion sum, its target and its residue), the four lanes split the
+// entry search (entries q, q + 4, ...) and exchange their results over DPP quad permutes: ~80 instructions per step.
+// Same arithmetic per channel and the same choice (lowest key, then lowest index), hence the same maps and records.
+// 512 threads = 128 rows in flight, as in k_dither (and for the same reason: see NT there).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v, int lane_in_quad) { // lane_in_quad: compile-time 0..2
+    return lane_in_quad == 0 ? (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x00, 0xf, 0xf, false)
+         : lane_in_quad == 1 ? (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x55, 0xf, 0xf, false)
+                             : (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xAA, 0xf, 0xf, false);
+}
+template <int SUB, int MODE>
+__global__ __launch_bounds__(512) void k_dither4(DitherParams P) {
+    constexpr int NT = 128; // rows in flight
+    __shared__ uint4 s_ent[256];
+    __shared__ double ring[NT][4][3];
+    __shared__ uint8_t s_tile[1024];
+    if (P.skip && *P.skip) return;
+    const int tid = threadIdx.x, j = tid >> 2, q = tid & 3;
+    const int c = q < 3 ? q : 2; // lane 3 shadows channel 2 (it only takes part in the entry search)
+    const int cand = (MODE == 2 && P.order) ? P.order[blockIdx.x] : (int)blockIdx.x;
+    constexpr int W = 256;
+    const int H = P.H;
+    const int sub_size = SUB ? SUB : P.sub_size;
+    for (int i = tid; i < P.ncol; i += 512) {
+        uint32_t col = P.pal_rgb8[i];
+        if ((uint32_t)i == P.slot_ci) col = __float_as_uint(P.cand_tab[8 * (size_t)cand + 6]);
+        const uint32_t r = col & 0xff, g = (col >> 8) & 0xff, b = (col >> 16) & 0xff;
+        s_ent[i] = make_uint4(r | (b << 16), (8u * (1024u + r)) | ((8u * (1534u - r)) << 16), g, col);
+    }
+    for (int i = tid; i < 1024; i += 512) s_tile[i] = P.tile_pal[i];
+    if (q < 3) for (int s4 = 0; s4 < 4; s4++) ring[j][s4][q] = 0.0;
+    __syncthreads();
+    const double w0 = 7.0 / 16.0, w1 = 3.0 / 16.0, w2 = 5.0 / 16.0, w3 = 1.0 / 16.0, mult = 0.8;
+    uint8_t *map = P.maps + (size_t)cand * W * H;
+    uint32_t *map4 = reinterpret_cast<uint32_t *>(map);
+    uint32_t *mapC4 = P.mapsC4 ? reinterpret_cast<uint32_t *>(P.mapsC4 + (size_t)cand * W * H) : nullptr;
+    int y0 = 0;
+    if (MODE == 2) {
+        const int g0 = P.first_group[P.first_k0 + cand];
+        y0 = min(4 * g0, H);
+        const uint32_t *b4 = reinterpret_cast<const uint32_t *>(P.bmap), *bC4 = reinterpret_cast<const uint32_t *>(P.bmapC4);
+        for (int i = tid; i < y0 * (W >> 2); i += 512) map4[i] = b4[i];
+        if (mapC4) for (int i = tid; i < y0 * (W >> 2); i += 512) { const int qq = i / y0, yy = i - qq * y0; mapC4[qq * H + yy] = bC4[qq * H + yy]; }
+        if (y0 >= H) return;
+    }
+    // MODE 2: B's checkpoint row reaches row-thread 0 through the ring of the last row-thread (see k_dither)
+    const bool ck_feed = MODE == 2 && j == NT - 1 && y0 > 0 && q < 3;
+    const double *ckp = MODE == 2 ? P.ck_in + (size_t)(y0 >> 2) * W * 3 : nullptr;
+    double ck_n = 0.0;
+    if (ck_feed) { ring[j][0][q] = ckp[q]; ring[j][1][q] = ckp[3 + q]; ck_n = ckp[6 + q]; }
+    __syncthreads();
+    const int nrows = H - y0;
+    const int rows_per_thread = (nrows + NT - 1) / NT;
+    const int nth = nrows < NT ? nrows : NT;
+    const int total_steps = 2 * (nth - 1) + rows_per_thread * W;
+    double left = 0.0; // v(x-1, y), this lane's channel
+    uint32_t macc = 0;
+    const int up = (j + NT - 1) & (NT - 1);
+    const uint4 *orig4 = reinterpret_cast<const uint4 *>(P.orig);
+    uint4 o_cur = make_uint4(0, 0, 0, 0), o_nxt = (y0 + j < H) ? orig4[(size_t)(y0 + j) * (W >> 2)] : make_uint4(0, 0, 0, 0);
+    for (int t = 0; t < total_steps; t++) {
+        const int local = t - 2 * j;
+        const int x = local & (W - 1), y = y0 + j + NT * (local >> 8);
+        const bool act = local >= 0 && local < rows_per_thread * W && y < H; // the same for the four lanes of a quad
+        if (act) {
+            const double r0 = ring[up][(x - 1) & 3][c], r1 = ring[up][x & 3][c], r2 = ring[up][(x + 1) & 3][c];
+            const int base = (int)s_tile[(x >> 3) + (y >> 3) * (W >> 3)] * sub_size;
+            if ((x & 3) == 0) {
+                o_cur = o_nxt;
+                const int ln = local + 4;
+                const int xn = ln & (W - 1), yn = y0 + j + NT * (ln >> 8);
+                if (ln < rows_per_thread * W && yn < H) o_nxt = orig4[((size_t)yn * W + xn) >> 2];
+            }
+            const uint32_t o = (x & 2) ? ((x & 1) ? o_cur.w : o_cur.z) : ((x & 1) ? o_cur.y : o_cur.x);
+            const bool opaque = (o >> 24) != 0;
+            const bool hasU = y > 0, hasL = x > 0, hasUL = hasU && hasL, hasUR = hasU && (x + 1 < W);
+            double acc = 0.0;
+            const double a0 = acc + r0 * mult * w3; acc = hasUL ? a0 : acc;
+            const double a1 = acc + r1 * mult * w2; acc = hasU ? a1 : acc;
+            const double a2 = acc + r2 * mult * w1; acc = hasUR ? a2 : acc;
+            const double a3 = acc + left * mult * w0; acc = hasL ? a3 : acc;
+            const double e = acc;
+            const double target = (double)((o >> (8 * c)) & 0xff) + acc;
+            const double cl = fmin(fmax(target, 0.0), 255.0);
+            const double tr = trunc(cl); // Rust f64::round: half away from zero (cl >= 0)
+            const uint32_t tqc = (uint32_t)(tr + ((cl - tr >= 0.5) ? 1.0 : 0.0));
+            const uint32_t tq0 = quad_bcast(tqc, 0), tq1 = quad_bcast(tqc, 1), tq2 = quad_bcast(tqc, 2);
+            // the quad's lanes take entries q, q + 4, ...: 8 * key each (dither_group_min's arithmetic), first minimum kept
+            const uint32_t t1 = tq0 | (tq2 << 16), tw = (8u * tq0) | ((0u - 8u * tq0) << 16);
+            const int tg = (int)tq1;
+            uint32_t bk = 0xffffffffu, bi = 0xffu;
+#pragma unroll 4
+            for (int i = 0; i < (SUB ? (SUB + 3) / 4 : 64); i++) {
+                const int idx = q + 4 * i;
+                if (idx >= sub_size) break;
+                const uint4 en = s_ent[base + idx];
+                const u16x2 d = as_u16x2(en.x) - as_u16x2(t1);
+                const u16x2 sq = d * d;
+                const u16x2 wg = as_u16x2(en.y) + as_u16x2(tw);
+                const int dg = (int)en.z - tg;
+                const uint32_t k8 = __builtin_amdgcn_udot2(sq, wg, (uint32_t)(dg * dg) << 14, false);
+                if (k8 < bk) { bk = k8; bi = (uint32_t)idx; }
+            }
+            { // lowest key, then lowest index, over the quad
+                uint32_t pk = (uint32_t)__builtin_amdgcn_mov_dpp((int)bk, 0xB1, 0xf, 0xf, false), pi = (uint32_t)__builtin_amdgcn_mov_dpp((int)bi, 0xB1, 0xf, 0xf, false);
+                if (pk < bk || (pk == bk && pi < bi)) { bk = pk; bi = pi; }
+                pk = (uint32_t)__builtin_amdgcn_mov_dpp((int)bk, 0x4E, 0xf, 0xf, false); pi = (uint32_t)__builtin_amdgcn_mov_dpp((int)bi, 0x4E, 0xf, 0xf, false);
+                if (pk < bk || (pk == bk && pi < bi)) { bk = pk; bi = pi; }
+            }
+            int best = (int)bi;
+            const uint32_t key_min = bk >> 3;
+            if (MODE == 1) { // B: the slot's entry is a stand-in for j0 (same colour, hence same key and same diffused error)
+                const bool in_sub = base == P.excl_sub * sub_size;
+                if (in_sub && best == P.excl_si) best = P.excl_j0;
+                if (q == 0) {
+                    const uint32_t thr = (in_sub && opaque) ? (sub_size == 1 ? 0xffffffffu : key_min + (P.excl_si < best ? 1u : 0u)) : 0u;
+                    const uint32_t ci = opaque ? (uint32_t)(base + best) : (uint32_t)P.ncol + 1u;
+                    P.rec_pack[(size_t)y * W + x] = (unsigned long long)(tq0 | (tq1 << 8) | (tq2 << 16) | (ci << 24)) | ((unsigned long long)thr << 32);
+                }
+            }
+            if (q == 0) {
+                const uint8_t m = opaque ? (uint8_t)best : 0;
+                macc = (macc >> 8) | ((uint32_t)m << 24);
+                if ((x & 3) == 3) {
+                    const size_t px = (size_t)y * W + x;
+                    map4[px >> 2] = macc;
+                    if (mapC4) mapC4[idx_c4(x & ~3, y, H) >> 2] = macc;
+                }
+            }
+            const uint32_t nc = s_ent[base + best].w;
+            const double dres = target - (double)((nc >> (8 * c)) & 0xff);
+            const double v = opaque ? dres : e; // transparent pixels forward their incoming error (lib.rs:469-474)
+            left = v;
+            if (q < 3) {
+                ring[j][x & 3][q] = v;
+                if (MODE == 1 && (y & 3) == 3 && y + 1 < H) P.ck_out[((size_t)((y + 1) >> 2) * W + x) * 3 + q] = v;
+            }
+        }
+        if (MODE == 2 && ck_feed && t + 2 < W) {
+            const int xc = t + 2;
+            ring[j][xc & 3][q] = ck_n;
+            if (xc + 1 < W) ck_n = ckp[3 * (xc + 1) + q];
+        }
+        __syncthreads();
+    }
+}
+
 // ---- the winner's map -----------------------------------------------------------------------------------
 // Each lane remembers the first-lowest error it has scored in the current candidate list and that candidate's map.
 struct BestRec { double err; int k; int pad; };
