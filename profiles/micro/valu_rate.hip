@@ -51,6 +51,21 @@ template <int KIND> void run(const char *name, int cus, double ghz) {
     CHECK(hipFree(out));
 }
 
+// the same chain on a grid of `blocks` one-wave blocks (a mostly idle chip): does a lone wave issue at the same rate?
+template <int KIND> void run_small(const char *name, int blocks, double ghz) {
+    float *out; CHECK(hipMalloc(&out, 4));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 3; rep++) {
+        CHECK(hipEventRecord(e0));
+        for (int i = 0; i < 20; i++) k_rate<KIND><<<blocks, 64>>>(out, 1.0f);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        const double per = ms / 20 * 1e6 / ((double)ITER * 16);
+        printf("%-14s %4d one-wave blocks: %.3f ns = %.2f cycles per wave-instruction (%.3f ms per launch)\n", name, blocks, per, per * ghz, ms / 20);
+    }
+    CHECK(hipFree(out));
+}
+
 int main() {
     hipDeviceProp_t pr; CHECK(hipGetDeviceProperties(&pr, 0));
     const double ghz = pr.clockRate * 1e-6;
@@ -65,5 +80,8 @@ int main() {
     run<7>("v_pk_mul_f32", pr.multiProcessorCount, ghz);
     run<8>("f32/f64 mixed", pr.multiProcessorCount, ghz);
     run<9>("v_cvt_f64_f32", pr.multiProcessorCount, ghz);
+    run_small<0>("v_fma_f32", 1, ghz);
+    run_small<0>("v_fma_f32", 12, ghz);
+    run_small<2>("v_fma_f64", 1, ghz);
     return 0;
 }
