@@ -590,6 +590,33 @@ def test_sparse_path_equals_dense_path(S, O, seed, variant, perceptual, monkeypa
     sparse.close()
 
 
+@pytest.mark.parametrize("count,size", [(8, 15), (4, 7)])
+def test_quad_dither_kernel_equals_the_one_lane_kernel(S, img256_alpha, count, size, monkeypatch):
+    """k_dither4 (a quad of lanes per row: channel per lane, the entry search split four ways) against k_dither (one lane per
+    row) in all three roles — the whole image (optimize), the base image B (records and checkpoints) and the resumed runs —
+    bit for bit: palette_map after optimize(), the candidates' errors, and the map the commit adopts."""
+    res = []
+    for quad in ("0", "1"):
+        monkeypatch.setenv("SNES_DITHER4", quad)
+        monkeypatch.setenv("SNES_DITHER4_MAX", "100000")
+        g = S.OptimizedImage(img256_alpha, count, size, dither=True)
+        if not res:
+            g.initialize_tiles()
+            g.recalculate_palettes()
+            tiles, pal = g.tile_palettes, g.palette
+        else:
+            g.tile_palettes, g.palette = tiles, pal
+        g.optimize()
+        m0 = g.palette_map.copy()
+        cand = S.random_candidates(77, 1 * size + 2, 300)
+        errs = g.score_candidates(1, 2, cand)
+        e, best = g.step(S.METHOD_RANDOM, 1, 2, 0, 77, 5, 300)
+        res.append((m0, errs, e, best, g.palette_map.copy()))
+        g.close()
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("seed,variant", [(0x5EED0000, 0), (0x5EED0001, 1)])
 def test_resumed_dither_equals_full_dither(S, O, seed, variant, monkeypatch):
     """--dither through causality: B dithered once per slot with the slot's entry out of play, every candidate resumed
