@@ -9,15 +9,17 @@
 //     scan lists the work items per (scale, first block), and every wave of sparse_h2_body starts all its rows at the
 //     same block.  On the BASELINE workload this removes ~40 % of the H pass's steps and of its output traffic.
 //   * H output leaves a wave as 128-byte lines (8 columns x 4 rows of one plane, staged through LDS) instead of the
-//     64-byte runs one column quad gives; the staging is kept that small (12 KB per wave) because the kernel is a chain
-//     of dependent iterations per wave and lives on the number of waves a CU holds.
-//   * At scale 0 the H pass also stores the XYB value it looked up for every pixel of a changed group (and B's H pass
-//     does for the whole of B), so the V pass reads its map input `img2` from a plane at every scale: it no longer
-//     touches the pack, the palette table or the won-pixel bitmap, and has one body for all scales.
+//     64-byte runs one column quad gives; LDS is kept that small (10 KB per wave: 15 waves per CU) because the kernel is a
+//     chain of dependent iterations per wave and lives on the number of waves a CU holds.
+//   * The H pass also stores the XYB value of every pixel of a changed group in the R4 layout (looked up here at scale 0,
+//     re-laid from the downscale's C4 copy at the other scales; B's H pass does scale 0 for the whole of B), so the V pass
+//     reads its map input `img2` from a plane at every scale: it no longer touches the pack, the palette table or the
+//     won-pixel bitmap, and has one body for all scales.
 //   * In sparse_v2_body a wave's 64 columns belong to one (candidate, channel), so the first changed group, the loop
-//     counter and the group -> storage choice are wave-uniform: base addresses live in SGPRs and every lane adds a
-//     32-bit byte offset (global loads in their scalar-base form) — the 64-bit per-lane address arithmetic and the
-//     pointer selects of the general body were a fifth of its instructions and the source of its register spills.
+//     counter and the group -> storage choice are wave-uniform: buffer loads with a uniform descriptor, a 32-bit lane
+//     offset and the group offset as the scalar offset — the 64-bit per-lane address arithmetic and the pointer selects of
+//     the general body were a fifth of its instructions and the source of its register spills.  Pairs run channel by
+//     channel, so that what a channel's waves share fits an XCD's L2.
 //     A wave reads a changed group from the candidate's own storage only if the group's first block is not to the
 //     right of the wave's columns; otherwise the candidate's H pass has not written those columns and they are B's.
 #pragma once
