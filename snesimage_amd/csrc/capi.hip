@@ -143,6 +143,7 @@ struct snesimage_ctx {
     struct Sparse {
         bool lpt = true; // V pass in descending sweep length (SNES_LPT=0: as listed)
         bool counters_cleared = false; // k_prep cleared B's counters for the current pack
+        uint32_t h2q_max = 512; // longest list that takes k_sparse_h2q (SNES_H2Q_MAX; 0 = never)
         uint32_t hgrid = 8192; // most blocks per scale of k_sparse_h (grid-stride beyond)
         bool enabled = false, side = true; uint32_t min_n = 64; uint32_t cap = 0; // cap = candidates per lane the arrays were sized for
         SparseGeom S{};
@@ -589,6 +590,10 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[1], stream));
     if (sp.side) HIPCHK(hipStreamWaitEvent(stream, sp.ev_base_h, 0)); // B's H-pass checkpoints (a short list gets here before B's sweep is through)
     { size_t gx = ((size_t)nc * (G.sh[0] / 4) * 3 + 15) / 16; if (gx > sp.hgrid) gx = sp.hgrid; // grid-stride over the item quads
+      if (nc <= sp.h2q_max) { // a short list: the H pass with a quad of lanes per row (a third of the chain, four times the waves)
+          size_t gq = ((size_t)nc * (G.sh[0] / 4) * 3 + 3) / 4; if (gq > sp.hgrid) gq = sp.hgrid;
+          hipLaunchKernelGGL(k_sparse_h2q, dim3((unsigned)gq, (unsigned)(P.s_first * kColBuckets)), dim3(64), h2_lds(c), stream, P);
+      } else
       hipLaunchKernelGGL(k_sparse_h2, dim3((unsigned)gx, (unsigned)(P.s_first * kColBuckets)), dim3(64), h2_lds(c), stream, P);
       if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((gx + 7) / 8), (unsigned)((G.nscales - P.s_first) * kColBuckets)), dim3(64), 0, stream, P); }
     if (sp.side || stream != c->stream) HIPCHK(hipStreamWaitEvent(stream, sp.side ? sp.ev_base_done : c->ev_ready, 0)); // checkpoints and H output of B
@@ -827,6 +832,7 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     if (const char *e = getenv("SNES_LPT")) c->sp.lpt = atoi(e) != 0;
     if (const char *e = getenv("SNES_DITHER4")) c->dither4 = atoi(e) != 0;
     if (const char *e = getenv("SNES_DITHER4_MAX")) { int v = atoi(e); if (v >= 0) c->dither4_max = (uint32_t)v; }
+    if (const char *e = getenv("SNES_H2Q_MAX")) { int v = atoi(e); if (v >= 0) c->sp.h2q_max = (uint32_t)v; }
     if (const char *e = getenv("SNES_HGRID")) { int v = atoi(e); if (v >= 1) c->sp.hgrid = (uint32_t)v; }
     if (const char *e = getenv("SNES_SPARSE_MIN")) { int v = atoi(e); if (v >= 1) c->sp.min_n = (uint32_t)v; }
     Geom &G = c->G;

@@ -203,6 +203,147 @@ __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int 
     }
 }
 
+// ---- the same H pass with a quad of lanes per row (candidates only; short lists) ---------------------------------------
+// sparse_h2_body runs the three planes of a row one after the other in one lane: ~300 instructions per column quad in one
+// chain, and a list that does not fill the chip is bound by the length of that chain (a wave alone issues an instruction
+// every ~2.6 ns).  Here lane q < 3 of a quad carries plane q of the row (its own six state floats) and lane 3 stages the XYB
+// plane; the inputs are fetched by all four (one address: one request).  Same values operation for operation.  A wave holds
+// four items instead of sixteen: four times the waves for the same list, which is why long lists keep the other body.
+template <bool S0>
+__device__ __forceinline__ void sparse_h2q_body(const SparseParams &P, const int list, const int bx, const int gx, H2Shared &sh) {
+    constexpr int NP = 4, PW = 32, ISTR = NP * PW + 4;
+    extern __shared__ float s_lut[];
+    const int lstr = P.ncol + 2;
+    float *const s_out = sh.out;
+    long long *const s_hbase = sh.hbase, *const s_xbase = sh.xbase;
+    const Geom &G = P.G;
+    const int s = list / kColBuckets, cb = list % kColBuckets;
+    const int W = G.sw[s], H = G.sh[s];
+    const int lane = threadIdx.x;
+    const int count = P.item_count[list];
+    if (bx * 4 >= count) return;
+    if (S0) {
+        for (int i = lane; i < 3 * lstr; i += 64) { const int c = i / lstr, j = i - c * lstr; s_lut[i] = P.pal_xyb[3 * j + c]; }
+        __syncthreads();
+    }
+    const int q = lane & 3, r = (lane >> 2) & 3, im = lane >> 4; // plane (3: the XYB plane), row of the group, item of the wave
+    const int pl = q < 3 ? q : 0;
+    const float n2_0 = P.K.n2[0], n2_1 = P.K.n2[1], n2_2 = P.K.n2[2];
+    const float mp_0 = -P.K.d1[0], mp_1 = -P.K.d1[1], mp_2 = -P.K.d1[2];
+    const int G4 = W >> 2, gs = cb << 4, gstart = gs >= 3 ? gs - 3 : 0;
+    for (int i0 = bx * 4; i0 < count; i0 += gx * 4) {
+        const int qi = i0 + im;
+        const bool valid = qi < count;
+        const unsigned int it = P.items[(size_t)list * P.item_stride + (valid ? qi : i0)];
+        const int k = (int)(it >> 8), j = (int)((it >> 2) & 63u), ch = (int)(it & 3u);
+        const CandMeta *M = P.meta + k;
+        const int y = 4 * (int)M->glist[P.S.goff[s] + j] + r;
+        const size_t ns = (size_t)W * H;
+        const float cand_v = S0 ? P.cand_tab[8 * (size_t)k + 3 + ch] : 0.0f;
+        const uint32_t crgb = S0 ? __float_as_uint(P.cand_tab[8 * (size_t)k + 6]) : 0u;
+        const float4 *in1 = reinterpret_cast<const float4 *>(P.img1C4 + G.src_off[s] + (size_t)ch * ns) + y;
+        const uint4 *pk = S0 ? reinterpret_cast<const uint4 *>(P.packC4) + 2 * (size_t)y : nullptr;
+        const bool um = S0 && P.use_maps;
+        const uint32_t *mw = um ? reinterpret_cast<const uint32_t *>(P.mapsC4 + (size_t)(k - P.k0) * ns) + y : nullptr;
+        const uint32_t *sw = um ? reinterpret_cast<const uint32_t *>(P.subC4) + y : nullptr;
+        const float4 *in2 = S0 ? nullptr
+                               : reinterpret_cast<const float4 *>(P.store + (size_t)k * P.S.cand_stride + P.S.off_xybC[s] + (size_t)j * 12 * W + (size_t)ch * 4 * W) + r;
+        __syncthreads(); // the previous round's flush has read the bases
+        if ((lane & 15) == 0) {
+            s_hbase[im] = valid ? (long long)k * P.S.cand_stride + P.S.off_hout[s] + (long long)j * 36 * W + (long long)(ch * 3) * 4 * W : -1ll;
+            s_xbase[im] = (long long)k * P.S.cand_stride + P.S.off_xybR[s] + (long long)j * 12 * W + (long long)ch * 4 * W;
+        }
+        float sa[3], sb[3]; // this lane's plane
+        const float *ck = P.ckh + P.S.off_ckh[s] + ((size_t)(ch * 3 + (cb > 0 ? cb - 1 : 0)) * 18) * H + y;
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            sa[e] = gs > 0 ? ck[(size_t)(pl * 6 + e) * H] : 0.0f;
+            sb[e] = gs > 0 ? ck[(size_t)(pl * 6 + 3 + e) * H] : 0.0f;
+        }
+        float4 r1[5], r2[5];
+#pragma unroll
+        for (int a = 0; a < 5; a++) { r1[a] = make_float4(0.f, 0.f, 0.f, 0.f); r2[a] = r1[a]; }
+        uint4 n_pa = make_uint4(0, 0, 0, 0), n_pb = n_pa;
+        r1[0] = in1[(size_t)gstart * H];
+        if (um) { n_pa.x = mw[(size_t)gstart * H]; n_pa.y = sw[(size_t)gstart * H]; }
+        else if (S0) { n_pa = pk[(size_t)gstart * H * 2]; n_pb = pk[(size_t)gstart * H * 2 + 1]; } else r2[0] = in2[(size_t)gstart * 4];
+        for (int g0 = gstart; g0 <= G4; g0 += 5) {
+#pragma unroll
+            for (int u = 0; u < 5; u++) {
+                const int g = g0 + u;
+                if (g > G4) break;
+                const int un = (u + 1) % 5, ua = (u + 2) % 5, ub = (u + 3) % 5, ul = (u + 4) % 5;
+                const uint4 c_pa = n_pa, c_pb = n_pb;
+                if (g + 1 < G4) {
+                    r1[un] = in1[(size_t)(g + 1) * H];
+                    if (um) { n_pa.x = mw[(size_t)(g + 1) * H]; n_pa.y = sw[(size_t)(g + 1) * H]; }
+                    else if (S0) { n_pa = pk[(size_t)(g + 1) * H * 2]; n_pb = pk[(size_t)(g + 1) * H * 2 + 1]; } else r2[un] = in2[(size_t)(g + 1) * 4];
+                } else { r1[un] = make_float4(0.f, 0.f, 0.f, 0.f); r2[un] = r1[un]; n_pa = make_uint4(0, 0, 0, 0); n_pb = n_pa; }
+                if (S0 && g < G4) {
+                    uint32_t c0, c1, c2, c3;
+                    if (P.use_maps) {
+                        uint32_t ci[4];
+                        resolve4_maps(c_pa.x, c_pa.y, P.slot_ci, (uint32_t)P.ncol, ci);
+                        c0 = ci[0]; c1 = ci[1]; c2 = ci[2]; c3 = ci[3];
+                    } else if (P.perceptual) {
+                        const int px0 = y * W + (g << 2);
+                        const uint32_t b4 = (P.bitmap[(size_t)k * (G.W * G.H / 32) + (px0 >> 5)] >> (px0 & 31)) & 0xfu;
+                        c0 = (b4 & 1u) ? (uint32_t)P.ncol : (c_pa.x >> 24); c1 = (b4 & 2u) ? (uint32_t)P.ncol : (c_pa.z >> 24);
+                        c2 = (b4 & 4u) ? (uint32_t)P.ncol : (c_pb.x >> 24); c3 = (b4 & 8u) ? (uint32_t)P.ncol : (c_pb.z >> 24);
+                    } else {
+                        c0 = sparse_ci(c_pa.x, c_pa.y, crgb, (uint32_t)P.ncol); c1 = sparse_ci(c_pa.z, c_pa.w, crgb, (uint32_t)P.ncol);
+                        c2 = sparse_ci(c_pb.x, c_pb.y, crgb, (uint32_t)P.ncol); c3 = sparse_ci(c_pb.z, c_pb.w, crgb, (uint32_t)P.ncol);
+                    }
+                    const float *lut = s_lut + ch * lstr;
+                    r2[u].x = c0 == (uint32_t)P.ncol ? cand_v : lut[c0]; r2[u].y = c1 == (uint32_t)P.ncol ? cand_v : lut[c1];
+                    r2[u].z = c2 == (uint32_t)P.ncol ? cand_v : lut[c2]; r2[u].w = c3 == (uint32_t)P.ncol ? cand_v : lut[c3];
+                }
+                if (g < gs) continue;
+                const float v1[4] = {r1[u].x, r1[u].y, r1[u].z, r1[u].w}, v2[4] = {r2[u].x, r2[u].y, r2[u].z, r2[u].w};
+                const float l1[4] = {r1[ua].z, r1[ua].w, r1[ub].x, r1[ub].y}, l2[4] = {r2[ua].z, r2[ua].w, r2[ub].x, r2[ub].y};
+                float outp[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    // this lane's plane: mu2 <- img2, s22 <- img2^2, s12 <- img1 * img2 (the same expressions as sparse_h2_body)
+                    const float s0 = l2[c] + v2[c];
+                    const float s1 = (l2[c] * l2[c]) + (v2[c] * v2[c]);
+                    const float s2 = (l1[c] * l2[c]) + (v1[c] * v2[c]);
+                    const float sum = q == 0 ? s0 : (q == 1 ? s1 : s2);
+                    if ((c & 1) == 0) { SNES_HSTEP(sum, sa, sb, outp[c]) } else { SNES_HSTEP(sum, sb, sa, outp[c]) }
+                }
+                if (g > gs) {
+                    float *so = s_out + im * ISTR + (((g - 1) & 1) << 4) + r + q * PW;
+                    if (q < 3) { so[0] = outp[0]; so[4] = outp[1]; so[8] = outp[2]; so[12] = outp[3]; }
+                    else { so[0] = r2[ul].x; so[4] = r2[ul].y; so[8] = r2[ul].z; so[12] = r2[ul].w; }
+                    if ((g & 1) == 0) {
+                        __syncthreads();
+                        const int x0 = (g - 2) << 2;
+                        const int half = lane >> 5, l = lane & 31, p = l >> 3, c = l & 7;
+                        const uint32_t o_l = (p == 3) ? (uint32_t)(x0 << 2) + (uint32_t)(c << 2) : (uint32_t)p * 4u * (uint32_t)W + (uint32_t)((x0 >> 6) << 8) + (uint32_t)((x0 & 63) << 2) + (uint32_t)(c << 2);
+#pragma unroll
+                        for (int m = 0; m < 4; m += 2) {
+                            const long long hb = s_hbase[m + half];
+                            if (hb >= 0) {
+                                const float4 v = *reinterpret_cast<const float4 *>(s_out + (m + half) * ISTR + l * 4);
+                                float *dst = P.store + ((p == 3) ? s_xbase[m + half] : hb) + o_l;
+                                *reinterpret_cast<float4 *>(dst) = v;
+                            }
+                        }
+                        __syncthreads();
+                    }
+                }
+            }
+        }
+    }
+}
+template <bool DUMMY>
+__device__ __forceinline__ void sparse_h2q_dispatch(const SparseParams &P, const int list, const int bx, const int gx) {
+    const int s = list / kColBuckets;
+    if (s >= P.G.nscales || P.G.sw[s] < 64 || (list % kColBuckets) >= (P.G.sw[s] >> 6)) return;
+    __shared__ H2Shared sh;
+    if (s == 0) sparse_h2q_body<true>(P, list, bx, gx, sh); else sparse_h2q_body<false>(P, list, bx, gx, sh);
+}
+
 // ---- V pass + maps of one (candidate, channel) per 64-column wave, resumed from B's checkpoint ------------------------------
 // Same checkpoint records, tail ring and pooling as sparse_v_body (kernels_sparse.hpp); W >= 64 only.
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -422,6 +563,7 @@ __device__ __forceinline__ void sparse_h2_dispatch(const SparseParams &P, const 
     if (s == 0) sparse_h2_body<true, BASE>(P, list, bx, gx, sh); else sparse_h2_body<false, BASE>(P, list, bx, gx, sh);
 }
 __global__ __launch_bounds__(64) void k_sparse_h2(SparseParams P) { sparse_h2_dispatch<false>(P, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x); }
+__global__ __launch_bounds__(64) void k_sparse_h2q(SparseParams P) { sparse_h2q_dispatch<true>(P, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x); } // short lists
 __global__ __launch_bounds__(64) void k_sparse_h2_base(SparseParams P) { sparse_h2_dispatch<true>(P, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x); }
 __global__ __launch_bounds__(256, 5) void k_sparse_v2(SparseParams P) { if ((int)blockIdx.y < P.G.nscales && P.G.sw[blockIdx.y] >= 64) sparse_v2_body<false>(P, (int)blockIdx.y, (int)blockIdx.x); }
 // B: the wide scales in this body (grid.y = scale), the narrow ones in the general one (grid.y = scale - s_first), two launches:
