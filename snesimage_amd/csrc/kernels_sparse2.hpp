@@ -260,25 +260,31 @@ __device__ __forceinline__ void sparse_h2q_body(const SparseParams &P, const int
             sa[e] = gs > 0 ? ck[(size_t)(pl * 6 + e) * H] : 0.0f;
             sb[e] = gs > 0 ? ck[(size_t)(pl * 6 + 3 + e) * H] : 0.0f;
         }
-        float4 r1[5], r2[5];
+        // six-slot ring: quads g-3 .. g+2; the inputs are fetched TWO quads ahead (a short list's waves are alone on their
+        // SIMDs: an iteration is a fraction of a memory round trip)
+        float4 r1[6], r2[6];
 #pragma unroll
-        for (int a = 0; a < 5; a++) { r1[a] = make_float4(0.f, 0.f, 0.f, 0.f); r2[a] = r1[a]; }
-        uint4 n_pa = make_uint4(0, 0, 0, 0), n_pb = n_pa;
-        r1[0] = in1[(size_t)gstart * H];
-        if (um) { n_pa.x = mw[(size_t)gstart * H]; n_pa.y = sw[(size_t)gstart * H]; }
-        else if (S0) { n_pa = pk[(size_t)gstart * H * 2]; n_pb = pk[(size_t)gstart * H * 2 + 1]; } else r2[0] = in2[(size_t)gstart * 4];
-        for (int g0 = gstart; g0 <= G4; g0 += 5) {
+        for (int a = 0; a < 6; a++) { r1[a] = make_float4(0.f, 0.f, 0.f, 0.f); r2[a] = r1[a]; }
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        uint4 n_pa = z4, n_pb = z4, m_pa = z4, m_pb = z4; // pack (or map) words of quads g+1 and g+2
+        auto fetch = [&](int gg, float4 &d1, float4 &d2, uint4 &pa, uint4 &pb) {
+            if (gg < G4) {
+                d1 = in1[(size_t)gg * H];
+                if (um) { pa.x = mw[(size_t)gg * H]; pa.y = sw[(size_t)gg * H]; }
+                else if (S0) { pa = pk[(size_t)gg * H * 2]; pb = pk[(size_t)gg * H * 2 + 1]; } else d2 = in2[(size_t)gg * 4];
+            } else { d1 = make_float4(0.f, 0.f, 0.f, 0.f); d2 = d1; pa = z4; pb = z4; }
+        };
+        fetch(gstart, r1[0], r2[0], n_pa, n_pb);
+        fetch(gstart + 1, r1[1], r2[1], m_pa, m_pb);
+        for (int g0 = gstart; g0 <= G4; g0 += 6) {
 #pragma unroll
-            for (int u = 0; u < 5; u++) {
+            for (int u = 0; u < 6; u++) {
                 const int g = g0 + u;
                 if (g > G4) break;
-                const int un = (u + 1) % 5, ua = (u + 2) % 5, ub = (u + 3) % 5, ul = (u + 4) % 5;
+                const int un2 = (u + 2) % 6, ua = (u + 3) % 6, ub = (u + 4) % 6, ul = (u + 5) % 6; // slots of quads g+2, g-3, g-2, g-1
                 const uint4 c_pa = n_pa, c_pb = n_pb;
-                if (g + 1 < G4) {
-                    r1[un] = in1[(size_t)(g + 1) * H];
-                    if (um) { n_pa.x = mw[(size_t)(g + 1) * H]; n_pa.y = sw[(size_t)(g + 1) * H]; }
-                    else if (S0) { n_pa = pk[(size_t)(g + 1) * H * 2]; n_pb = pk[(size_t)(g + 1) * H * 2 + 1]; } else r2[un] = in2[(size_t)(g + 1) * 4];
-                } else { r1[un] = make_float4(0.f, 0.f, 0.f, 0.f); r2[un] = r1[un]; n_pa = make_uint4(0, 0, 0, 0); n_pb = n_pa; }
+                n_pa = m_pa; n_pb = m_pb;
+                fetch(g + 2, r1[un2], r2[un2], m_pa, m_pb);
                 if (S0 && g < G4) {
                     uint32_t c0, c1, c2, c3;
                     if (P.use_maps) {
