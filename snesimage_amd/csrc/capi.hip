@@ -543,7 +543,8 @@ int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si) {
         if (sp.side) { HIPCHK(hipEventRecord(sp.ev_base_in, c->stream)); HIPCHK(hipStreamWaitEvent(bs, sp.ev_base_in, 0)); }
         hipLaunchKernelGGL(k_sparse_scan, dim3(1), dim3(1024), 0, bs, P); // B's work items (every group, from column 0): only B's own sweeps read them
         // wide scales: B rows start at column 0 (list s*kColBuckets) and leave the per-block H checkpoints and the scale-0 XYB plane
-        hipLaunchKernelGGL(k_sparse_h2_base, dim3((unsigned)((G.sh[0] / 4 * 3 + 15) / 16), (unsigned)(P.s_first * kColBuckets)), dim3(64), h2_lds(c), bs, P);
+        if (sp.h2q_max > 0) hipLaunchKernelGGL(k_sparse_h2q_base, dim3((unsigned)((G.sh[0] / 4 * 3 + 3) / 4), (unsigned)(P.s_first * kColBuckets)), dim3(64), h2_lds(c), bs, P);
+        else hipLaunchKernelGGL(k_sparse_h2_base, dim3((unsigned)((G.sh[0] / 4 * 3 + 15) / 16), (unsigned)(P.s_first * kColBuckets)), dim3(64), h2_lds(c), bs, P);
         if (sp.side) HIPCHK(hipEventRecord(sp.ev_base_h, bs)); // the candidates' H pass resumes from the block checkpoints this launch leaves
         // the wide scales' V sweep first: the candidates' V pass (the bulk of a call) waits for it alone; the narrow scales'
         // sweeps follow and are awaited by the candidates' narrow V pass at the very end of the launch group

@@ -203,15 +203,15 @@ __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int 
     }
 }
 
-// ---- the same H pass with a quad of lanes per row (candidates only; short lists) ---------------------------------------
+// ---- the same H pass with a quad of lanes per row (short lists, and B: a single image is one) --------------------------
 // sparse_h2_body runs the three planes of a row one after the other in one lane: ~300 instructions per column quad in one
 // chain, and a list that does not fill the chip is bound by the length of that chain (a wave alone issues an instruction
 // every ~2.6 ns).  Here lane q < 3 of a quad carries plane q of the row (its own six state floats) and lane 3 stages the XYB
 // plane; the inputs are fetched by all four (one address: one request).  Same values operation for operation.  A wave holds
 // four items instead of sixteen: four times the waves for the same list, which is why long lists keep the other body.
-template <bool S0>
+template <bool S0, bool BASE>
 __device__ __forceinline__ void sparse_h2q_body(const SparseParams &P, const int list, const int bx, const int gx, H2Shared &sh) {
-    constexpr int NP = 4, PW = 32, ISTR = NP * PW + 4;
+    constexpr int NP = (S0 || !BASE) ? 4 : 3, PW = 32, ISTR = 4 * PW + 4; // (the XYB planes of B above scale 0 come from its downscale)
     extern __shared__ float s_lut[];
     const int lstr = P.ncol + 2;
     float *const s_out = sh.out;
@@ -239,12 +239,13 @@ __device__ __forceinline__ void sparse_h2q_body(const SparseParams &P, const int
         const CandMeta *M = P.meta + k;
         const int y = 4 * (int)M->glist[P.S.goff[s] + j] + r;
         const size_t ns = (size_t)W * H;
-        const float cand_v = S0 ? P.cand_tab[8 * (size_t)k + 3 + ch] : 0.0f;
-        const uint32_t crgb = S0 ? __float_as_uint(P.cand_tab[8 * (size_t)k + 6]) : 0u;
+        const float cand_v = (S0 && !BASE) ? P.cand_tab[8 * (size_t)k + 3 + ch] : 0.0f;
+        const uint32_t crgb = (S0 && !BASE) ? __float_as_uint(P.cand_tab[8 * (size_t)k + 6]) : 0u;
+        const uint32_t never = BASE ? 0u : 0xffffffffu; // thr & never == 0 for B: it wins nothing
         const float4 *in1 = reinterpret_cast<const float4 *>(P.img1C4 + G.src_off[s] + (size_t)ch * ns) + y;
         const uint4 *pk = S0 ? reinterpret_cast<const uint4 *>(P.packC4) + 2 * (size_t)y : nullptr;
         const bool um = S0 && P.use_maps;
-        const uint32_t *mw = um ? reinterpret_cast<const uint32_t *>(P.mapsC4 + (size_t)(k - P.k0) * ns) + y : nullptr;
+        const uint32_t *mw = um ? reinterpret_cast<const uint32_t *>(BASE ? P.bmapC4 : P.mapsC4 + (size_t)(k - P.k0) * ns) + y : nullptr;
         const uint32_t *sw = um ? reinterpret_cast<const uint32_t *>(P.subC4) + y : nullptr;
         const float4 *in2 = S0 ? nullptr
                                : reinterpret_cast<const float4 *>(P.store + (size_t)k * P.S.cand_stride + P.S.off_xybC[s] + (size_t)j * 12 * W + (size_t)ch * 4 * W) + r;
@@ -289,22 +290,27 @@ __device__ __forceinline__ void sparse_h2q_body(const SparseParams &P, const int
                     uint32_t c0, c1, c2, c3;
                     if (P.use_maps) {
                         uint32_t ci[4];
-                        resolve4_maps(c_pa.x, c_pa.y, P.slot_ci, (uint32_t)P.ncol, ci);
+                        resolve4_maps(c_pa.x, c_pa.y, BASE ? 0xffffffffu : P.slot_ci, (uint32_t)P.ncol, ci);
                         c0 = ci[0]; c1 = ci[1]; c2 = ci[2]; c3 = ci[3];
-                    } else if (P.perceptual) {
+                    } else if (P.perceptual && !BASE) {
                         const int px0 = y * W + (g << 2);
                         const uint32_t b4 = (P.bitmap[(size_t)k * (G.W * G.H / 32) + (px0 >> 5)] >> (px0 & 31)) & 0xfu;
                         c0 = (b4 & 1u) ? (uint32_t)P.ncol : (c_pa.x >> 24); c1 = (b4 & 2u) ? (uint32_t)P.ncol : (c_pa.z >> 24);
                         c2 = (b4 & 4u) ? (uint32_t)P.ncol : (c_pb.x >> 24); c3 = (b4 & 8u) ? (uint32_t)P.ncol : (c_pb.z >> 24);
                     } else {
-                        c0 = sparse_ci(c_pa.x, c_pa.y, crgb, (uint32_t)P.ncol); c1 = sparse_ci(c_pa.z, c_pa.w, crgb, (uint32_t)P.ncol);
-                        c2 = sparse_ci(c_pb.x, c_pb.y, crgb, (uint32_t)P.ncol); c3 = sparse_ci(c_pb.z, c_pb.w, crgb, (uint32_t)P.ncol);
+                        c0 = sparse_ci(c_pa.x, c_pa.y & never, crgb, (uint32_t)P.ncol); c1 = sparse_ci(c_pa.z, c_pa.w & never, crgb, (uint32_t)P.ncol);
+                        c2 = sparse_ci(c_pb.x, c_pb.y & never, crgb, (uint32_t)P.ncol); c3 = sparse_ci(c_pb.z, c_pb.w & never, crgb, (uint32_t)P.ncol);
                     }
                     const float *lut = s_lut + ch * lstr;
                     r2[u].x = c0 == (uint32_t)P.ncol ? cand_v : lut[c0]; r2[u].y = c1 == (uint32_t)P.ncol ? cand_v : lut[c1];
                     r2[u].z = c2 == (uint32_t)P.ncol ? cand_v : lut[c2]; r2[u].w = c3 == (uint32_t)P.ncol ? cand_v : lut[c3];
                 }
                 if (g < gs) continue;
+                if (BASE && q < 3 && g > 0 && (g & 15) == 0 && g < G4 && valid) { // B: the state of this plane on entering block g/16
+                    float *co = P.ckh + P.S.off_ckh[s] + ((size_t)(ch * 3 + (g >> 4) - 1) * 18) * H + y;
+#pragma unroll
+                    for (int e = 0; e < 3; e++) { co[(size_t)(pl * 6 + e) * H] = sa[e]; co[(size_t)(pl * 6 + 3 + e) * H] = sb[e]; }
+                }
                 const float v1[4] = {r1[u].x, r1[u].y, r1[u].z, r1[u].w}, v2[4] = {r2[u].x, r2[u].y, r2[u].z, r2[u].w};
                 const float l1[4] = {r1[ua].z, r1[ua].w, r1[ub].x, r1[ub].y}, l2[4] = {r2[ua].z, r2[ua].w, r2[ub].x, r2[ub].y};
                 float outp[4];
@@ -320,7 +326,7 @@ __device__ __forceinline__ void sparse_h2q_body(const SparseParams &P, const int
                 if (g > gs) {
                     float *so = s_out + im * ISTR + (((g - 1) & 1) << 4) + r + q * PW;
                     if (q < 3) { so[0] = outp[0]; so[4] = outp[1]; so[8] = outp[2]; so[12] = outp[3]; }
-                    else { so[0] = r2[ul].x; so[4] = r2[ul].y; so[8] = r2[ul].z; so[12] = r2[ul].w; }
+                    else if (NP == 4) { so[0] = r2[ul].x; so[4] = r2[ul].y; so[8] = r2[ul].z; so[12] = r2[ul].w; }
                     if ((g & 1) == 0) {
                         __syncthreads();
                         const int x0 = (g - 2) << 2;
@@ -329,7 +335,7 @@ __device__ __forceinline__ void sparse_h2q_body(const SparseParams &P, const int
 #pragma unroll
                         for (int m = 0; m < 4; m += 2) {
                             const long long hb = s_hbase[m + half];
-                            if (hb >= 0) {
+                            if (hb >= 0 && l < NP * 8) {
                                 const float4 v = *reinterpret_cast<const float4 *>(s_out + (m + half) * ISTR + l * 4);
                                 float *dst = P.store + ((p == 3) ? s_xbase[m + half] : hb) + o_l;
                                 *reinterpret_cast<float4 *>(dst) = v;
@@ -342,12 +348,12 @@ __device__ __forceinline__ void sparse_h2q_body(const SparseParams &P, const int
         }
     }
 }
-template <bool DUMMY>
+template <bool BASE>
 __device__ __forceinline__ void sparse_h2q_dispatch(const SparseParams &P, const int list, const int bx, const int gx) {
     const int s = list / kColBuckets;
     if (s >= P.G.nscales || P.G.sw[s] < 64 || (list % kColBuckets) >= (P.G.sw[s] >> 6)) return;
     __shared__ H2Shared sh;
-    if (s == 0) sparse_h2q_body<true>(P, list, bx, gx, sh); else sparse_h2q_body<false>(P, list, bx, gx, sh);
+    if (s == 0) sparse_h2q_body<true, BASE>(P, list, bx, gx, sh); else sparse_h2q_body<false, BASE>(P, list, bx, gx, sh);
 }
 
 // ---- V pass + maps of one (candidate, channel) per 64-column wave, resumed from B's checkpoint ------------------------------
@@ -569,7 +575,8 @@ __device__ __forceinline__ void sparse_h2_dispatch(const SparseParams &P, const 
     if (s == 0) sparse_h2_body<true, BASE>(P, list, bx, gx, sh); else sparse_h2_body<false, BASE>(P, list, bx, gx, sh);
 }
 __global__ __launch_bounds__(64) void k_sparse_h2(SparseParams P) { sparse_h2_dispatch<false>(P, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x); }
-__global__ __launch_bounds__(64) void k_sparse_h2q(SparseParams P) { sparse_h2q_dispatch<true>(P, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x); } // short lists
+__global__ __launch_bounds__(64) void k_sparse_h2q(SparseParams P) { sparse_h2q_dispatch<false>(P, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x); } // short lists
+__global__ __launch_bounds__(64) void k_sparse_h2q_base(SparseParams P) { sparse_h2q_dispatch<true>(P, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x); } // B: a single image is a short list
 __global__ __launch_bounds__(64) void k_sparse_h2_base(SparseParams P) { sparse_h2_dispatch<true>(P, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x); }
 __global__ __launch_bounds__(256, 5) void k_sparse_v2(SparseParams P) { if ((int)blockIdx.y < P.G.nscales && P.G.sw[blockIdx.y] >= 64) sparse_v2_body<false>(P, (int)blockIdx.y, (int)blockIdx.x); }
 // B: the wide scales in this body (grid.y = scale), the narrow ones in the general one (grid.y = scale - s_first), two launches:
