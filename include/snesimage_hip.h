@@ -99,6 +99,41 @@ int32_t snesimage_step_begin(snesimage_ctx *ctx, uint32_t method, uint32_t palet
                              uint32_t shard_rank, uint32_t shard_count, double *d_errors);
 int32_t snesimage_step_commit(snesimage_ctx *ctx, const double *d_errors);
 
+/* Speculative multi-slot stepping — the reference's own loop (lib.rs:888-933: one call of optimize_palette_entry_random
+ * with 64 candidates, lib.rs:191-240, or _channel with 32, lib.rs:286-328, or _nes with 56, lib.rs:242-284, per scheduler
+ * slot), several calls per launch.  Call j+1 of that loop sees the state call j saw whenever call j accepted nothing
+ * (strict <, lib.rs:216-219), so a *window* scores the next K calls of the schedule against the current palette in one set
+ * of launches, applies their decisions in order and stops behind the first call that changed the state; the calls behind
+ * it are void and are scored again by the next window.  Bit-identical to snesimage_schedule_next + snesimage_step per
+ * call, for every K.  Windows cover the group-sparse path (256 rows, no dither); other configurations are stepped call
+ * by call inside snesimage_run_slots. */
+typedef struct { double error; int32_t best_k; uint8_t rgb5[3]; uint8_t changed; } snesimage_call_result; /* what snesimage_last_step reports after the call */
+typedef struct {
+    uint32_t calls, accepted, windows, reserved; /* calls that took effect; calls that changed the palette; launch sets */
+    uint64_t scored, useful;                     /* candidates scored in all; candidates of the calls that took effect */
+} snesimage_run_stats;
+/* n_calls calls from scheduler state (*palette, *index, *channel, *step) — advanced as by snesimage_schedule_next — call j
+ * drawing its random candidates from stream (seed, first_step_id + j).  window: calls per launch set (0 = adaptive: doubles
+ * after a clean window up to SNES_WINDOW_MAX, default 64, falls back to the run length seen; 1 = call by call).
+ * log (optional): n_calls records.  stats (optional). */
+int32_t snesimage_run_slots(snesimage_ctx *ctx, uint32_t n_calls, uint64_t seed, uint64_t first_step_id, uint32_t *palette,
+                            uint32_t *index, uint32_t *channel, uint32_t *step, uint32_t window,
+                            snesimage_call_result *log, snesimage_run_stats *stats);
+/* Allocate the storage of windows of up to n_slots calls now instead of on first use (about 0.3 GB of HBM per call; the
+ * library never takes more than SNES_WINDOW_MAX, default 64, calls per window). */
+int32_t snesimage_slots_reserve(snesimage_ctx *ctx, uint32_t n_slots);
+/* The two phases of one window, for sharding its calls over GPUs (call j of the window -> rank j % shard_count: its own base
+ * image, its own candidates).  Phase 1 takes at most n_slots calls from the given scheduler state — fewer where the method
+ * changes, all calls of a window having the same number of candidates (*stride) — and writes errors[j * stride + k]
+ * (device, n_slots * 64 doubles; +inf for calls of other ranks; NULL = the context's own vector, single rank only).  The
+ * caller min-all-reduces the first *n_taken * *stride doubles, then phase 2 commits identically on every rank: *consumed
+ * calls took effect, *accepted = the last of them changed the palette; log (host, optional): *n_taken records. */
+int32_t snesimage_slots_begin(snesimage_ctx *ctx, uint32_t n_slots, uint64_t seed, uint64_t first_step_id, uint32_t palette,
+                              uint32_t index, uint32_t channel, uint32_t step, uint32_t n_random, uint32_t shard_rank,
+                              uint32_t shard_count, double *d_errors, uint32_t *n_taken, uint32_t *stride);
+int32_t snesimage_slots_commit(snesimage_ctx *ctx, const double *d_errors, uint32_t *consumed, uint32_t *accepted,
+                               snesimage_call_result *log);
+
 /* One process, several GPUs: a group borrows one context per device, all created from the same image and brought to
  * the same state (initialise one, copy tile_palettes and palette to the others, optimize()).  snesimage_group_step is
  * snesimage_step with the candidates sharded over the members (rank r scores k = r mod N): step_begin on every member,

@@ -17,6 +17,19 @@ _u64p = C.POINTER(C.c_uint64)
 _f32p = C.POINTER(C.c_float)
 _f64p = C.POINTER(C.c_double)
 
+
+
+class CallResult(C.Structure):
+    """snesimage_call_result: what snesimage_last_step reports after one optimizer call."""
+    _fields_ = [("error", C.c_double), ("best_k", C.c_int32), ("rgb5", C.c_uint8 * 3), ("changed", C.c_uint8)]
+
+
+class RunStats(C.Structure):
+    """snesimage_run_stats"""
+    _fields_ = [("calls", C.c_uint32), ("accepted", C.c_uint32), ("windows", C.c_uint32), ("reserved", C.c_uint32),
+                ("scored", C.c_uint64), ("useful", C.c_uint64)]
+
+
 # every symbol include/snesimage_hip.h declares: (name, restype, argtypes)
 SIGNATURES = [
     ("snesimage_create", C.c_int32, [_u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32,
@@ -42,6 +55,12 @@ SIGNATURES = [
     ("snesimage_step_begin", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                          C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     ("snesimage_step_commit", C.c_int32, [C.c_void_p, C.c_void_p]),
+    ("snesimage_run_slots", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, _u32p, _u32p, _u32p, _u32p, C.c_uint32,
+                                        C.POINTER(CallResult), C.POINTER(RunStats)]),
+    ("snesimage_slots_reserve", C.c_int32, [C.c_void_p, C.c_uint32]),
+    ("snesimage_slots_begin", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, _u32p, _u32p]),
+    ("snesimage_slots_commit", C.c_int32, [C.c_void_p, C.c_void_p, _u32p, _u32p, C.POINTER(CallResult)]),
     ("snesimage_group_create", C.c_int32, [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_void_p)]),
     ("snesimage_group_destroy", None, [C.c_void_p]),
     ("snesimage_group_step", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32,

@@ -158,6 +158,37 @@ class OptimizedImage:
         self._chk(self._L.snesimage_last_step(self._c, C.byref(err), _p(best, _ffi._u8p), C.byref(k)))
         return err.value, best, k.value
 
+    def run_slots(self, n_calls, seed=1, first_step_id=0, state=(0, 0, 0, 0), window=0, want_log=True):
+        """The reference's loop (lib.rs:888-933) for n_calls calls from scheduler state (palette, index, channel, step),
+        speculatively several calls per launch (bit-identical to `step` per scheduled call).  Returns (log, state, stats):
+        log[j] = (error, best_k, rgb5, changed) after call j."""
+        st = [C.c_uint32(int(v)) for v in state]
+        log = (_ffi.CallResult * n_calls)() if want_log else None
+        stats = _ffi.RunStats()
+        self._chk(self._L.snesimage_run_slots(self._c, n_calls, seed, first_step_id, C.byref(st[0]), C.byref(st[1]), C.byref(st[2]),
+                                              C.byref(st[3]), int(window), log, C.byref(stats)))
+        out = [(r.error, r.best_k, np.array(r.rgb5[:], np.uint8), int(r.changed)) for r in log] if want_log else None
+        return out, tuple(v.value for v in st), {k: getattr(stats, k) for k in ("calls", "accepted", "windows", "scored", "useful")}
+
+    def slots_reserve(self, n_slots):
+        """Allocate the storage of windows of up to n_slots calls now instead of on first use."""
+        self._chk(self._L.snesimage_slots_reserve(self._c, int(n_slots)))
+
+    def slots_begin(self, n_slots, seed, first_step_id, state, n_random=0, shard_rank=0, shard_count=1, d_errors_ptr=0):
+        """Phase 1 of a slot window -> (calls taken, candidates per call)."""
+        taken, stride = C.c_uint32(0), C.c_uint32(0)
+        self._chk(self._L.snesimage_slots_begin(self._c, n_slots, seed, first_step_id, state[0], state[1], state[2], state[3], n_random,
+                                                shard_rank, shard_count, C.c_void_p(d_errors_ptr or 0), C.byref(taken), C.byref(stride)))
+        return taken.value, stride.value
+
+    def slots_commit(self, d_errors_ptr=0, n_taken=0):
+        """Phase 2 -> (calls consumed, accepted flag, log of the consumed calls)."""
+        used, acc = C.c_uint32(0), C.c_uint32(0)
+        log = (_ffi.CallResult * max(1, n_taken))() if n_taken else None
+        self._chk(self._L.snesimage_slots_commit(self._c, C.c_void_p(d_errors_ptr or 0), C.byref(used), C.byref(acc), log))
+        out = [(r.error, r.best_k, np.array(r.rgb5[:], np.uint8), int(r.changed)) for r in log[:used.value]] if log else None
+        return used.value, acc.value, out
+
     def step_begin(self, method, palette, index, channel, seed, step_id, n_total, shard_rank, shard_count,
                    d_errors_ptr):
         self._chk(self._L.snesimage_step_begin(self._c, method, palette, index, channel, seed, step_id, n_total,

@@ -170,6 +170,7 @@ struct snesimage_ctx {
     struct snesimage_batch *owner = nullptr; // set while the context is lent to a batch (batch_host.inc)
     struct snesimage_group *group = nullptr; // set while the context is a member of a group (group_host.inc)
     hipEvent_t ev_own = nullptr;             // marks the end of the work this context queued on its own stream (for its batch)
+    struct snesimage_window *win = nullptr;  // slot windows of snesimage_run_slots (window_host.inc), created on first use
 
     // cache keys
     bool tables_valid = false, src_valid = false, inc_valid = false;
@@ -914,9 +915,11 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
 
 void batch_forget(struct snesimage_batch *b, snesimage_ctx *c);
 void group_forget(struct snesimage_group *g, snesimage_ctx *c);
+namespace { void window_free(struct snesimage_window *w); }
 void snesimage_destroy(snesimage_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->win) { if (c->stream) (void)hipStreamSynchronize(c->stream); window_free(c->win); c->win = nullptr; } // its slot contexts borrow this context's planes
     if (c->owner) batch_forget(c->owner, c); // waits for the batch's stream and retires the batch
     if (c->group) group_forget(c->group, c); // retires the group: its other members are their own again
     if (c->ev_own) (void)hipEventDestroy(c->ev_own);
@@ -1330,4 +1333,5 @@ int32_t snesimage_debug_math(int32_t device, int32_t op, const float *x, const f
 } // extern "C"
 
 #include "batch_host.inc"
+#include "window_host.inc"
 #include "group_host.inc"

@@ -65,4 +65,55 @@ __global__ __launch_bounds__(256) void kb_commit(const BatchArgs *__restrict__ A
 #undef SNES_BATCH_IMG
 #undef SNES_BATCH_XCD
 
+// ---- speculative slot window (snesimage_run_slots, window_host.inc) ----------------------------------------------------
+// K consecutive calls of the reference's scheduler (lib.rs:888-933) are scored against the SAME palette, one "image" of
+// the batched launches per call (a slot context: its own pack, base image B and candidate storage; source pyramid,
+// palette and tables shared).  Call j+1 of the sequential loop sees exactly this state iff call j accepted nothing, so
+// the calls are committed in order and the window ends at the first one that changes the state: bit-identical to the
+// one-call-at-a-time loop, whatever K.
+struct WindowSlot { int method, n, slot, channel, nes, pad; unsigned long long key; };
+struct WindowResult { int consumed, accepted; };
+constexpr int kMaxWindow = 256;
+
+// The candidate lists of all K calls (every rank generates all of them: the commit needs the winner's colour wherever it
+// was scored) and the error vector preset to +inf (a rank fills in the calls it owns; the others arrive by min-all-reduce).
+__global__ void kw_gen_candidates(const WindowSlot *__restrict__ S, const uint8_t *__restrict__ colors, uint8_t *__restrict__ cand, double *__restrict__ errors, int stride) {
+    const WindowSlot w = S[blockIdx.y];
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < stride) errors[(size_t)blockIdx.y * stride + k] = __longlong_as_double(0x7ff0000000000000ll);
+    gen_candidates_body(w.method, w.n, w.key, colors, w.slot, w.channel, cand + 3 * (size_t)blockIdx.y * stride, 0, 1, nullptr, nullptr);
+}
+
+// In-order commit: per call the first-lowest error (one wave per call, lexicographic (error, index) minimum: what the
+// ascending strict-< scan of lib.rs:216-219 ends on), then one thread applies the calls' decisions in sequence and stops
+// behind the first call that changed the state (a candidate accepted; for the NES method, which always takes its table
+// argmin, a colour that differs from the current one).  log[j] = what snesimage_last_step would report after call j.
+__global__ __launch_bounds__(1024) void kw_commit(const WindowSlot *__restrict__ S, int K, int stride, const double *__restrict__ errors, const uint8_t *__restrict__ cand, uint8_t *__restrict__ colors,
+                                                 double *__restrict__ inc_err, StepResult *__restrict__ last, PaletteTables T, WindowResult *__restrict__ res, StepResult *__restrict__ log) {
+    __shared__ double s_e[kMaxWindow];
+    __shared__ int s_k[kMaxWindow];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int j = w; j < K; j += 16) {
+        const int n = S[j].n;
+        double be = __longlong_as_double(0x7ff0000000000000ll); int bk = 0x7fffffff;
+        for (int k = lane; k < n; k += 64) { const double e = errors[(size_t)j * stride + k]; if (e < be) { be = e; bk = k; } } // NaN never wins, as in the reference
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double e2 = __shfl_xor(be, o); const int k2 = __shfl_xor(bk, o);
+            if (e2 < be || (e2 == be && k2 < bk)) { be = e2; bk = k2; }
+        }
+        if (lane == 0) { s_e[j] = be; s_k[j] = bk; }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    int consumed = 0, accepted = 0;
+    for (int j = 0; j < K && !accepted; j++) {
+        commit_decide(s_e[j], s_k[j], cand + 3 * (size_t)j * stride, colors, S[j].slot, S[j].nes, inc_err, log + j, T);
+        consumed = j + 1;
+        accepted = S[j].nes ? (log[j].changed ? 1 : 0) : (log[j].best_k >= 0 ? 1 : 0);
+    }
+    res->consumed = consumed; res->accepted = accepted;
+    if (consumed) *last = log[consumed - 1];
+}
+
 } // namespace snes

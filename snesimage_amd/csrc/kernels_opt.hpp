@@ -530,28 +530,14 @@ __global__ void k_shard_select(const uint8_t *__restrict__ cand, int n, int rank
 // Acceptance rule: ascending k, strict `<` against the running best starting from the incumbent
 // (lib.rs:216-219, 302-305) or from f64::MAX for the NES method (lib.rs:250, 258-261).
 struct PaletteTables { const float *eotf, *lab_eotf; uint32_t *rgb8; float *lin, *xyb, *lab; }; // lab == nullptr without --perceptual-palettes
-__device__ __forceinline__ void commit_body(const double *__restrict__ errors, int n, const uint8_t *__restrict__ cand, uint8_t *__restrict__ colors, int slot, int nes, double *__restrict__ inc_err,
-                                            StepResult *__restrict__ last, const PaletteTables &T) {
-    // The sequential scan "for k ascending: if e_k < best" ends on the FIRST index attaining the minimum, provided that
-    // minimum is < the starting value; a parallel (error, index) lexicographic minimum gives the same answer.
-    __shared__ double s_e[256];
-    __shared__ int s_k[256];
-    const int t = threadIdx.x;
-    double be = __longlong_as_double(0x7ff0000000000000ll); int bk = 0x7fffffff;
-    for (int k = t; k < n; k += 256) { const double e = errors[k]; if (e < be) { be = e; bk = k; } } // NaN never wins, as in the reference
-    s_e[t] = be; s_k[t] = bk;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if (t < st) {
-            const double e2 = s_e[t + st]; const int k2 = s_k[t + st];
-            if (e2 < s_e[t] || (e2 == s_e[t] && k2 < s_k[t])) { s_e[t] = e2; s_k[t] = k2; }
-        }
-        __syncthreads();
-    }
-    if (t != 0) return;
+// The decision of one optimizer call given the first-lowest error (min_e at index min_k; min_k = 0x7fffffff: no finite
+// error) of its candidate list: accept it iff it is strictly below the incumbent (always, for the NES method), write
+// the slot's colour and its rows of the palette tables, leave the committed state's error in *inc_err.  One thread.
+__device__ __forceinline__ void commit_decide(const double min_e, const int min_k, const uint8_t *__restrict__ cand, uint8_t *__restrict__ colors, int slot, int nes, double *__restrict__ inc_err,
+                                              StepResult *__restrict__ last, const PaletteTables &T) {
     const double start = nes ? 1.7976931348623157e308 : *inc_err;
     double best = start; int best_k = -1;
-    if (s_k[0] != 0x7fffffff && s_e[0] < start) { best = s_e[0]; best_k = s_k[0]; }
+    if (min_k != 0x7fffffff && min_e < start) { best = min_e; best_k = min_k; }
     uint8_t c[3] = {colors[3 * slot], colors[3 * slot + 1], colors[3 * slot + 2]};
     uint8_t changed = 0;
     if (nes && best_k < 0) best_k = 0; // best_index = 0 (lib.rs:249)
@@ -576,6 +562,28 @@ __device__ __forceinline__ void commit_body(const double *__restrict__ errors, i
         if (best < 1.7976931348623157e308) *inc_err = best; // error() of the committed state (lib.rs:910)
     }
     last->error = *inc_err; last->best_k = best_k; last->rgb5[0] = c[0]; last->rgb5[1] = c[1]; last->rgb5[2] = c[2]; last->changed = changed;
+}
+
+__device__ __forceinline__ void commit_body(const double *__restrict__ errors, int n, const uint8_t *__restrict__ cand, uint8_t *__restrict__ colors, int slot, int nes, double *__restrict__ inc_err,
+                                            StepResult *__restrict__ last, const PaletteTables &T) {
+    // The sequential scan "for k ascending: if e_k < best" ends on the FIRST index attaining the minimum, provided that
+    // minimum is < the starting value; a parallel (error, index) lexicographic minimum gives the same answer.
+    __shared__ double s_e[256];
+    __shared__ int s_k[256];
+    const int t = threadIdx.x;
+    double be = __longlong_as_double(0x7ff0000000000000ll); int bk = 0x7fffffff;
+    for (int k = t; k < n; k += 256) { const double e = errors[k]; if (e < be) { be = e; bk = k; } } // NaN never wins, as in the reference
+    s_e[t] = be; s_k[t] = bk;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (t < st) {
+            const double e2 = s_e[t + st]; const int k2 = s_k[t + st];
+            if (e2 < s_e[t] || (e2 == s_e[t] && k2 < s_k[t])) { s_e[t] = e2; s_k[t] = k2; }
+        }
+        __syncthreads();
+    }
+    if (t != 0) return;
+    commit_decide(s_e[0], s_k[0], cand, colors, slot, nes, inc_err, last, T);
 }
 
 // ---- deterministic-math probes for the bit-parity tests -------------------------------------------
