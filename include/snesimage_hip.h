@@ -109,7 +109,8 @@ int32_t snesimage_step_commit(snesimage_ctx *ctx, const double *d_errors);
  * by call inside snesimage_run_slots. */
 typedef struct { double error; int32_t best_k; uint8_t rgb5[3]; uint8_t changed; } snesimage_call_result; /* what snesimage_last_step reports after the call */
 typedef struct {
-    uint32_t calls, accepted, windows, reserved; /* calls that took effect; calls that changed the palette; launch sets */
+    uint32_t calls, accepted, windows, voided;   /* calls that took effect; calls that changed the palette; launch sets collected;
+                                                  * launch sets enqueued ahead and voided on the device (they scored nothing) */
     uint64_t scored, useful;                     /* candidates scored in all; candidates of the calls that took effect */
 } snesimage_run_stats;
 /* n_calls calls from scheduler state (*palette, *index, *channel, *step) — advanced as by snesimage_schedule_next — call j

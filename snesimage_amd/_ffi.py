@@ -26,7 +26,7 @@ class CallResult(C.Structure):
 
 class RunStats(C.Structure):
     """snesimage_run_stats"""
-    _fields_ = [("calls", C.c_uint32), ("accepted", C.c_uint32), ("windows", C.c_uint32), ("reserved", C.c_uint32),
+    _fields_ = [("calls", C.c_uint32), ("accepted", C.c_uint32), ("windows", C.c_uint32), ("voided", C.c_uint32),
                 ("scored", C.c_uint64), ("useful", C.c_uint64)]
 
 

@@ -168,7 +168,7 @@ class OptimizedImage:
         self._chk(self._L.snesimage_run_slots(self._c, n_calls, seed, first_step_id, C.byref(st[0]), C.byref(st[1]), C.byref(st[2]),
                                               C.byref(st[3]), int(window), log, C.byref(stats)))
         out = [(r.error, r.best_k, np.array(r.rgb5[:], np.uint8), int(r.changed)) for r in log] if want_log else None
-        return out, tuple(v.value for v in st), {k: getattr(stats, k) for k in ("calls", "accepted", "windows", "scored", "useful")}
+        return out, tuple(v.value for v in st), {k: getattr(stats, k) for k in ("calls", "accepted", "windows", "voided", "scored", "useful")}
 
     def slots_reserve(self, n_slots):
         """Allocate the storage of windows of up to n_slots calls now instead of on first use."""

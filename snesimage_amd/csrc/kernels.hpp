@@ -147,7 +147,7 @@ __device__ __forceinline__ void prep_body(const PrepParams &P) {
     }
     unsigned long long w = (unsigned long long)(rgb | (ci << 24)) | ((unsigned long long)thr << 32);
     P.pack[px] = w;
-    P.packT[(size_t)x * P.H + y] = w;
+    if (P.packT) P.packT[(size_t)x * P.H + y] = w; // (the transposed copy feeds the general H pass only: slot contexts have none)
     P.packC4[idx_c4(x, y, P.H)] = w;
     P.packR4[idx_r4(x, y, P.W)] = w;
     if (P.subC4) { const uint8_t sbv = opaque ? (uint8_t)base : (uint8_t)255; P.subC4[idx_c4(x, y, P.H)] = sbv; P.subR4[idx_r4(x, y, P.W)] = sbv; }

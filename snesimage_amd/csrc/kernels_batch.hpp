@@ -16,7 +16,8 @@ struct BatchArgs {
     const float *lab_eotf; float *cand_lab; // --perceptual-palettes
 };
 
-#define SNES_BATCH_IMG const BatchArgs &a = A[blockIdx.z]
+// `dead` (optional device flag): nonzero = this launch belongs to a slot window that an earlier window has voided: leave at once
+#define SNES_BATCH_IMG if (dead && *dead) return; const BatchArgs &a = A[blockIdx.z]
 // XCD-aware block -> (image, x, y) mapping for the heavy stages.  Blocks are dealt round-robin over the chip's 8 XCDs, each
 // with its own L2; with blockIdx.z = image every XCD would see every image and fetch its base image, checkpoints and source
 // planes (~20 MB per image) once per XCD (PMC: 2.25 MB fetched per candidate in the V pass against 0.37 MB in single-image
@@ -34,34 +35,34 @@ __device__ __forceinline__ BatchBlock batch_block() {
     b.x = rem % X; b.y = rem / X;
     return b;
 }
-#define SNES_BATCH_XCD const BatchBlock bb = batch_block(); const BatchArgs &a = A[bb.img]
-__global__ void kb_gen_candidates(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; gen_candidates_body(a.method, a.n, a.key, a.colors_in, a.slot, a.channel, a.cand, 0, 1, nullptr, nullptr); }
-__global__ __launch_bounds__(256) void kb_prep(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; prep_body(a.prep); }
-__global__ __launch_bounds__(256) void kb_build_plist(const BatchArgs *__restrict__ A) {
+#define SNES_BATCH_XCD if (dead && *dead) return; const BatchBlock bb = batch_block(); const BatchArgs &a = A[bb.img]
+__global__ void kb_gen_candidates(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; gen_candidates_body(a.method, a.n, a.key, a.colors_in, a.slot, a.channel, a.cand, 0, 1, nullptr, nullptr); }
+__global__ __launch_bounds__(256) void kb_prep(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; prep_body(a.prep); }
+__global__ __launch_bounds__(256) void kb_build_plist(const BatchArgs *__restrict__ A, const int *__restrict__ dead) {
     SNES_BATCH_IMG;
     build_plist_body(a.Pb.pack, a.npx, const_cast<uint4 *>(a.Pb.plist), const_cast<int *>(a.Pb.plist_count));
 }
-__global__ __launch_bounds__(1024) void kb_sparse_scan(const BatchArgs *__restrict__ A, int base) { SNES_BATCH_IMG; sparse_scan_body(base ? a.Pb : a.Pc); }
-__global__ __launch_bounds__(256) void kb_base_down(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; base_down_body(a.Pb); }
-__global__ __launch_bounds__(256) void kb_sparse_down(const BatchArgs *__restrict__ A) { SNES_BATCH_XCD; sparse_down_body(a.Pc, 0, bb.x); }
-__global__ void kb_candidate_tables(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; candidate_tables_body(a.cand, a.n, a.eotf, a.cand_tab); }
-__global__ void kb_candidate_lab(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; candidate_lab_body(a.cand_tab, a.n, a.lab_eotf, a.cand_lab); }
-__global__ __launch_bounds__(256) void kb_clear_bitmaps(const BatchArgs *__restrict__ A) { // the won-pixel bitmaps of the call's candidates (npx/32 words each)
+__global__ __launch_bounds__(1024) void kb_sparse_scan(const BatchArgs *__restrict__ A, int base, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_scan_body(base ? a.Pb : a.Pc); }
+__global__ __launch_bounds__(256) void kb_base_down(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; base_down_body(a.Pb); }
+__global__ __launch_bounds__(256) void kb_sparse_down(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_down_body(a.Pc, 0, bb.x); }
+__global__ void kb_candidate_tables(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; candidate_tables_body(a.cand, a.n, a.eotf, a.cand_tab); }
+__global__ void kb_candidate_lab(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; candidate_lab_body(a.cand_tab, a.n, a.lab_eotf, a.cand_lab); }
+__global__ __launch_bounds__(256) void kb_clear_bitmaps(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { // the won-pixel bitmaps of the call's candidates (npx/32 words each)
     SNES_BATCH_IMG;
     const size_t words = (size_t)a.n * (a.npx / 32);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) a.Pc.bitmap[i] = 0u;
 }
-__global__ __launch_bounds__(256) void kb_sparse_scan_lab(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; sparse_scan_lab_body(a.Pc); }
-__global__ __launch_bounds__(64) void kb_sparse_h(const BatchArgs *__restrict__ A, int base) { SNES_BATCH_IMG; sparse_h_body(base ? a.Pb : a.Pc); }
-__global__ __launch_bounds__(64) void kb_sparse_h2(const BatchArgs *__restrict__ A) { SNES_BATCH_XCD; sparse_h2_dispatch<false>(a.Pc, bb.y, bb.x, (int)gridDim.x); }
-__global__ __launch_bounds__(64) void kb_sparse_h2_base(const BatchArgs *__restrict__ A) { SNES_BATCH_XCD; sparse_h2_dispatch<true>(a.Pb, bb.y, bb.x, (int)gridDim.x); }
-__global__ __launch_bounds__(256, 5) void kb_sparse_v2(const BatchArgs *__restrict__ A) { SNES_BATCH_XCD; if (bb.y < a.Pc.G.nscales && a.Pc.G.sw[bb.y] >= 64) sparse_v2_body<false>(a.Pc, bb.y, bb.x); }
-__global__ __launch_bounds__(256) void kb_sparse_v_base(const BatchArgs *__restrict__ A) { SNES_BATCH_XCD; if (bb.y < a.Pb.G.nscales && a.Pb.G.sw[bb.y] >= 64) sparse_v2_body<true>(a.Pb, bb.y, bb.x); }
-__global__ __launch_bounds__(256, 1) void kb_sparse_v_base_narrow(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; sparse_v_base_narrow_dispatch(a.Pb); }
-__global__ __launch_bounds__(1024) void kb_sparse_order(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; sparse_order_body(a.Pc, const_cast<int *>(a.Pc.order)); }
-__global__ __launch_bounds__(256, 2) void kb_sparse_v(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; sparse_v_body<false, 2, 2>(a.Pc, (int)blockIdx.y + a.Pc.s_first); }
-__global__ void kb_final_score(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; final_score_body(a.part, a.n, a.Pc.G, a.errors, 1, 0, a.Pc.item_count, (int)kItemLists); }
-__global__ __launch_bounds__(256) void kb_commit(const BatchArgs *__restrict__ A) { SNES_BATCH_IMG; commit_body(a.errors, a.n, a.cand, a.colors, a.slot, a.nes, a.inc_err, a.last, a.T); }
+__global__ __launch_bounds__(256) void kb_sparse_scan_lab(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_scan_lab_body(a.Pc); }
+__global__ __launch_bounds__(64) void kb_sparse_h(const BatchArgs *__restrict__ A, int base, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_h_body(base ? a.Pb : a.Pc); }
+__global__ __launch_bounds__(64) void kb_sparse_h2(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_h2_dispatch<false>(a.Pc, bb.y, bb.x, (int)gridDim.x); }
+__global__ __launch_bounds__(64) void kb_sparse_h2_base(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_h2_dispatch<true>(a.Pb, bb.y, bb.x, (int)gridDim.x); }
+__global__ __launch_bounds__(256, 5) void kb_sparse_v2(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; if (bb.y < a.Pc.G.nscales && a.Pc.G.sw[bb.y] >= 64) sparse_v2_body<false>(a.Pc, bb.y, bb.x); }
+__global__ __launch_bounds__(256) void kb_sparse_v_base(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; if (bb.y < a.Pb.G.nscales && a.Pb.G.sw[bb.y] >= 64) sparse_v2_body<true>(a.Pb, bb.y, bb.x); }
+__global__ __launch_bounds__(256, 1) void kb_sparse_v_base_narrow(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_v_base_narrow_dispatch(a.Pb); }
+__global__ __launch_bounds__(1024) void kb_sparse_order(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_order_body(a.Pc, const_cast<int *>(a.Pc.order)); }
+__global__ __launch_bounds__(256, 2) void kb_sparse_v(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_v_body<false, 2, 2>(a.Pc, (int)blockIdx.y + a.Pc.s_first); }
+__global__ void kb_final_score(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; final_score_body(a.part, a.n, a.Pc.G, a.errors, 1, 0, a.Pc.item_count, (int)kItemLists); }
+__global__ __launch_bounds__(256) void kb_commit(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; commit_body(a.errors, a.n, a.cand, a.colors, a.slot, a.nes, a.inc_err, a.last, a.T); }
 #undef SNES_BATCH_IMG
 #undef SNES_BATCH_XCD
 
@@ -77,7 +78,8 @@ constexpr int kMaxWindow = 256;
 
 // The candidate lists of all K calls (every rank generates all of them: the commit needs the winner's colour wherever it
 // was scored) and the error vector preset to +inf (a rank fills in the calls it owns; the others arrive by min-all-reduce).
-__global__ void kw_gen_candidates(const WindowSlot *__restrict__ S, const uint8_t *__restrict__ colors, uint8_t *__restrict__ cand, double *__restrict__ errors, int stride) {
+__global__ void kw_gen_candidates(const WindowSlot *__restrict__ S, const uint8_t *__restrict__ colors, uint8_t *__restrict__ cand, double *__restrict__ errors, int stride, const int *__restrict__ dead) {
+    if (*dead) return;
     const WindowSlot w = S[blockIdx.y];
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < stride) errors[(size_t)blockIdx.y * stride + k] = __longlong_as_double(0x7ff0000000000000ll);
@@ -89,7 +91,8 @@ __global__ void kw_gen_candidates(const WindowSlot *__restrict__ S, const uint8_
 // behind the first call that changed the state (a candidate accepted; for the NES method, which always takes its table
 // argmin, a colour that differs from the current one).  log[j] = what snesimage_last_step would report after call j.
 __global__ __launch_bounds__(1024) void kw_commit(const WindowSlot *__restrict__ S, int K, int stride, const double *__restrict__ errors, const uint8_t *__restrict__ cand, uint8_t *__restrict__ colors,
-                                                 double *__restrict__ inc_err, StepResult *__restrict__ last, PaletteTables T, WindowResult *__restrict__ res, StepResult *__restrict__ log) {
+                                                 double *__restrict__ inc_err, StepResult *__restrict__ last, PaletteTables T, WindowResult *__restrict__ res, StepResult *__restrict__ log, int *__restrict__ dead) {
+    if (*dead) { if (threadIdx.x == 0) { res->consumed = 0; res->accepted = 0; } return; } // voided by an earlier window's commit: nothing of this one happened
     __shared__ double s_e[kMaxWindow];
     __shared__ int s_k[kMaxWindow];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(1024) void kw_commit(const WindowSlot *__restrict__
         accepted = S[j].nes ? (log[j].changed ? 1 : 0) : (log[j].best_k >= 0 ? 1 : 0);
     }
     res->consumed = consumed; res->accepted = accepted;
+    if (accepted) *dead = 1; // windows already enqueued behind this one were built for the old palette
     if (consumed) *last = log[consumed - 1];
 }
 
