@@ -171,6 +171,7 @@ struct snesimage_ctx {
     struct snesimage_group *group = nullptr; // set while the context is a member of a group (group_host.inc)
     hipEvent_t ev_own = nullptr;             // marks the end of the work this context queued on its own stream (for its batch)
     struct snesimage_window *win = nullptr;  // slot windows of snesimage_run_slots (window_host.inc), created on first use
+    bool pack_borrowed = false;              // a slot context of a --dither window: pack and subpalette planes are the parent's
 
     // cache keys
     bool tables_valid = false, src_valid = false, inc_valid = false;

@@ -14,6 +14,9 @@ struct BatchArgs {
     const double *part; double *errors; double *inc_err; StepResult *last; PaletteTables T;
     int method, n, slot, channel, nes, npx;
     const float *lab_eotf; float *cand_lab; // --perceptual-palettes
+    // --dither (slot windows): Floyd-Steinberg of the call's base image B (k_dither4 MODE 1: the slot's entry stands in for
+    // entry j0 of its subpalette, colour bcolor -> table row btab) and the candidates' resumed runs (MODE 2)
+    DitherParams Db, Dc; const unsigned long long *win_pack; const uint8_t *bcolor; float *btab; int *zero; int nzero;
 };
 
 // `dead` (optional device flag): nonzero = this launch belongs to a slot window that an earlier window has voided: leave at once
@@ -40,8 +43,19 @@ __global__ void kb_gen_candidates(const BatchArgs *__restrict__ A, const int *__
 __global__ __launch_bounds__(256) void kb_prep(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; prep_body(a.prep); }
 __global__ __launch_bounds__(256) void kb_build_plist(const BatchArgs *__restrict__ A, const int *__restrict__ dead) {
     SNES_BATCH_IMG;
-    build_plist_body(a.Pb.pack, a.npx, const_cast<uint4 *>(a.Pb.plist), const_cast<int *>(a.Pb.plist_count));
+    build_plist_body(a.win_pack ? a.win_pack : a.Pb.pack, a.npx, const_cast<uint4 *>(a.Pb.plist), const_cast<int *>(a.Pb.plist_count)); // (--dither: B's record of targets and keys to beat)
 }
+// --dither: what k_prep does for the other paths — B's item counters and the contested-pixel count cleared — and B's row of the candidate table
+__global__ void kb_dither_prep(const BatchArgs *__restrict__ A, const int *__restrict__ dead) {
+    SNES_BATCH_IMG;
+    if ((int)threadIdx.x < a.nzero) a.zero[threadIdx.x] = 0;
+    candidate_tables_body(a.bcolor, 1, a.eotf, a.btab);
+}
+template <int SUB> __global__ __launch_bounds__(512) void kb_dither_base(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; dither4_body<SUB, 1>(a.Db, 0); }
+__global__ __launch_bounds__(1024) void kb_dither_first(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; dither_first_body(a.Pc); }
+template <int SUB> __global__ __launch_bounds__(512) void kb_dither_run4(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; dither4_body<SUB, 2>(a.Dc, (int)blockIdx.x); }
+template <int SUB> __global__ __launch_bounds__(128) void kb_dither_run(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; dither_body<false, SUB, 2>(a.Dc, (int)blockIdx.x); }
+__global__ __launch_bounds__(1024) void kb_dither_diff(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; dither_diff_body(a.Pc); }
 __global__ __launch_bounds__(1024) void kb_sparse_scan(const BatchArgs *__restrict__ A, int base, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_scan_body(base ? a.Pb : a.Pc); }
 __global__ __launch_bounds__(256) void kb_base_down(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; base_down_body(a.Pb); }
 __global__ __launch_bounds__(256) void kb_sparse_down(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_down_body(a.Pc, 0, bb.x); }
@@ -118,6 +132,25 @@ __global__ __launch_bounds__(1024) void kw_commit(const WindowSlot *__restrict__
     res->consumed = consumed; res->accepted = accepted;
     if (accepted) *dead = 1; // windows already enqueued behind this one were built for the old palette
     if (consumed) *last = log[consumed - 1];
+}
+
+// --dither: the committed state's palette_map (lib.rs:237 re-runs optimize() on the winner's palette).  The winner's own
+// resumed run IS that map: adopted if its call was scored on this rank (call j -> rank j % count, slot context j / count);
+// *skip = 1 then, and also when nothing was accepted (the stored map stands); 0 = the caller has to dither again.
+__global__ __launch_bounds__(1024) void kw_take_map(const BatchArgs *__restrict__ A, int rank, int count, const WindowResult *__restrict__ res, const StepResult *__restrict__ log,
+                                                   uint8_t *__restrict__ map, int npx, int *__restrict__ skip) {
+    const int consumed = res->consumed, accepted = res->accepted;
+    int have = 1;
+    if (accepted) {
+        const int j = consumed - 1, k = log[j].best_k;
+        have = (j % count == rank) ? 1 : 0;
+        if (have) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(A[j / count].Pc.maps + (size_t)k * npx);
+            uint4 *dst = reinterpret_cast<uint4 *>(map);
+            for (int i = threadIdx.x; i < npx / 16; i += 1024) dst[i] = src[i];
+        }
+    }
+    if (threadIdx.x == 0) *skip = have;
 }
 
 } // namespace snes

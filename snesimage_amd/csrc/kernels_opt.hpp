@@ -101,7 +101,7 @@ __device__ __forceinline__ uint32_t dither_group_min(const uint4 *__restrict__ e
 //     block's last thread, 2 (NT - 1) steps behind: its ring still holds the columns needed only if 2 (NT - 1) >= W - 2, i.e.
 //     NT = 128 at W = 256 (a 64-thread variant is not merely slower, it is wrong).
 template <bool PERC, int SUB, int MODE = 0, int NT = 128>
-__global__ __launch_bounds__(NT) void k_dither(DitherParams P) {
+__device__ __forceinline__ void dither_body(const DitherParams &P, const int blk) { // blk: the launch's block index (blockIdx.x unless the caller batches over z)
     static_assert(2 * (NT - 1) >= 256 - 2, "the wavefront's ring is four columns deep: see NT above");
     __shared__ uint4 s_ent[256];
     __shared__ float s_lab[PERC ? 256 * 3 : 1];
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(NT) void k_dither(DitherParams P) {
     __shared__ uint8_t s_tile[1024];
     if (P.skip && *P.skip) return;
     const int j = threadIdx.x;
-    const int cand = (MODE == 2 && P.order) ? P.order[blockIdx.x] : (int)blockIdx.x;
+    const int cand = (MODE == 2 && P.order) ? P.order[blk] : blk;
     constexpr int W = 256; // snesimage_create admits no other width; a constant keeps the per-step index arithmetic to shifts
     const int H = P.H;
     const int sub_size = SUB ? SUB : P.sub_size;
@@ -288,7 +288,7 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v, int lane_in_quad) { /
                              : (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xAA, 0xf, 0xf, false);
 }
 template <int SUB, int MODE>
-__global__ __launch_bounds__(512) void k_dither4(DitherParams P) {
+__device__ __forceinline__ void dither4_body(const DitherParams &P, const int blk) {
     constexpr int NT = 128; // rows in flight
     __shared__ uint4 s_ent[256];
     __shared__ double ring[NT][4][3];
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(512) void k_dither4(DitherParams P) {
     if (P.skip && *P.skip) return;
     const int tid = threadIdx.x, j = tid >> 2, q = tid & 3;
     const int c = q < 3 ? q : 2; // lane 3 shadows channel 2 (it only takes part in the entry search)
-    const int cand = (MODE == 2 && P.order) ? P.order[blockIdx.x] : (int)blockIdx.x;
+    const int cand = (MODE == 2 && P.order) ? P.order[blk] : blk;
     constexpr int W = 256;
     const int H = P.H;
     const int sub_size = SUB ? SUB : P.sub_size;
@@ -819,6 +819,10 @@ __global__ void k_tile_move(const double *__restrict__ cost, const int *__restri
 }
 
 // ---- kernel entry points of the bodies above ----
+template <bool PERC, int SUB, int MODE = 0, int NT = 128>
+__global__ __launch_bounds__(NT) void k_dither(DitherParams P) { dither_body<PERC, SUB, MODE, NT>(P, (int)blockIdx.x); }
+template <int SUB, int MODE>
+__global__ __launch_bounds__(512) void k_dither4(DitherParams P) { dither4_body<SUB, MODE>(P, (int)blockIdx.x); }
 __global__ void k_gen_candidates(int method, int n, unsigned long long key, const uint8_t *__restrict__ colors, int slot, int channel, uint8_t *__restrict__ cand,
                                  int rank = 0, int count = 1, uint8_t *__restrict__ sel = nullptr, double *__restrict__ errors = nullptr) {
     gen_candidates_body(method, n, key, colors, slot, channel, cand, rank, count, sel, errors);
