@@ -55,6 +55,7 @@ void usage() {
             "Options:\n  -c, --subpalette-count <N>  [default: 1]\n  -s, --subpalette-size <N>   [default: 7]\n"
             "  -d, --dither\n      --perceptual-palettes\n      --nes\n"
             "      --calls <N>          optimizer calls to run [default: 0]\n      --candidates <N>     random candidates per call [default: 64]\n"
+            "      --window <N>         optimizer calls scored per launch set (0 = adaptive, 1 = call by call; same result) [default: 0]\n"
             "      --seed <N>           candidate RNG seed [default: 1]\n      --device <N>         HIP device [default: 0]\n"
             "      --devices <A,B,..>   shard every call's candidates over these devices (RCCL inside the library)\n"
             "      --tile-palettes <F>  1024-byte tile->subpalette override\n      --resume <F>         start from the palette and tile palettes of a previous JSON output\n"
@@ -104,7 +105,7 @@ void synth(uint64_t seed, uint32_t w, uint32_t h, std::vector<uint8_t> &out) { /
 
 int main(int argc, char **argv) {
     std::vector<std::string> pos;
-    uint32_t count = 1, size = 7, flags = 0, calls = 0, ncand = 64, reassign_every = 0; // src/config.rs:13-18 defaults
+    uint32_t count = 1, size = 7, flags = 0, calls = 0, ncand = 64, reassign_every = 0, window = 0; // src/config.rs:13-18 defaults
     uint64_t seed = 1;
     int device = 0;
     std::string tile_file, preview_file, resume_file;
@@ -121,6 +122,7 @@ int main(int argc, char **argv) {
         else if (a == "--calls") calls = (uint32_t)strtoul(need("--calls"), nullptr, 10);
         else if (a == "--candidates") ncand = (uint32_t)strtoul(need("--candidates"), nullptr, 10);
         else if (a == "--seed") seed = strtoull(need("--seed"), nullptr, 0);
+        else if (a == "--window") window = (uint32_t)strtoul(need("--window"), nullptr, 10);
         else if (a == "--device") device = atoi(need("--device"));
         else if (a == "--devices") { for (const char *q = need("--devices"); *q;) { char *end = nullptr; devices.push_back((int)strtol(q, &end, 10)); if (end == q) { fprintf(stderr, "error: invalid value for '--devices'\n"); return 2; } q = *end == ',' ? end + 1 : end; } }
         else if (a == "--tile-palettes") tile_file = need("--tile-palettes");
@@ -220,27 +222,71 @@ int main(int argc, char **argv) {
     uint32_t palette = 0, index = 0, channel = 0, step = 0, sweep = 0;
     double last_error = 1.7976931348623157e308;
     std::vector<uint8_t> before(3 * (size_t)count * size), after(before.size());
-    for (uint32_t call = 0; call < calls; call++) {
-        uint32_t p = palette, ix = index, ch = channel, method = 0;
-        snesimage_schedule_next(count, size, (flags & SNES_NES) ? 1 : 0, &palette, &index, &channel, &step, &method);
-        snesimage_get_palette_rgb5(ctx, before.data());
-        double error = 0.0; uint8_t best[3];
-        const int32_t rc = group ? snesimage_group_step(group, method, p, ix, ch, seed, call, method == SNES_METHOD_RANDOM ? ncand : 0, &error, best)
-                                 : snesimage_step(ctx, method, p, ix, ch, seed, call, method == SNES_METHOD_RANDOM ? ncand : 0, &error, best);
-        if (rc != 0) die(std::string("Unable to optimize palette: ") + snesimage_last_error());
-        const uint8_t *b = &before[3 * ((size_t)p * size + ix)];
+    const int nes = (flags & SNES_NES) ? 1 : 0;
+    auto report = [&](uint32_t p, uint32_t ix, const uint8_t *b, const uint8_t *best, double error) {
         if (b[0] != best[0] || b[1] != best[1] || b[2] != best[2]) { // src/lib.rs:222-234
             char m[160];
             snprintf(m, sizeof m, "Setting color (%u, %u) from (%u, %u, %u) to (%u, %u, %u)", p, ix, b[0], b[1], b[2], best[0], best[1], best[2]);
             log_info(m);
         }
         if (std::abs(error - last_error) > 2.220446049250313e-16) { log_info("Current Error: " + fmt_f64(error)); last_error = error; } // src/lib.rs:912-915
+    };
+    auto end_of_sweep = [&]() {
         if (reassign_every && step != sweep && step % reassign_every == 0) { // a sweep over every slot has just ended (src/lib.rs:925-931)
             uint32_t moved = 0;
             for (snesimage_ctx *m : members) if (snesimage_reassign_tiles(m, &moved) != 0) die(std::string("Unable to reassign tiles: ") + snesimage_last_error());
             log_info("Reassigned " + std::to_string(moved) + " tiles");
         }
         sweep = step;
+    };
+    if (!group && ncand == 64 && window != 1) {
+        // The reference's loop (src/lib.rs:888-933), several calls per launch: snesimage_run_slots scores the coming calls of the
+        // schedule against the current palette and applies them in order up to the first one that changes it — the same
+        // trajectory, call for call, as stepping one call at a time (--window 1).  A run ends with its sweep when tiles are
+        // to be reassigned between sweeps.
+        std::vector<snesimage_call_result> log;
+        if (snesimage_get_palette_rgb5(ctx, before.data()) != 0) die(snesimage_last_error());
+        snesimage_run_stats total{};
+        for (uint32_t call = 0; call < calls;) {
+            uint32_t n = calls - call;
+            if (n > 4096) n = 4096;
+            if (reassign_every) { // calls left in the current sweep
+                uint32_t p = palette, ix = index, ch = channel, st = step, m = 0, k = 0;
+                while (st == step && k < n) { snesimage_schedule_next(count, size, nes, &p, &ix, &ch, &st, &m); k++; }
+                n = k;
+            }
+            log.resize(n);
+            uint32_t p = palette, ix = index, ch = channel, st = step, method = 0;
+            snesimage_run_stats rs{};
+            if (snesimage_run_slots(ctx, n, seed, call, &palette, &index, &channel, &step, window, log.data(), &rs) != 0) die(std::string("Unable to optimize palette: ") + snesimage_last_error());
+            total.calls += rs.calls; total.accepted += rs.accepted; total.windows += rs.windows; total.scored += rs.scored; total.useful += rs.useful;
+            for (uint32_t j = 0; j < n; j++) {
+                const uint32_t cp = p, ci = ix;
+                snesimage_schedule_next(count, size, nes, &p, &ix, &ch, &st, &method);
+                uint8_t *b = &before[3 * ((size_t)cp * size + ci)];
+                report(cp, ci, b, log[j].rgb5, log[j].error);
+                b[0] = log[j].rgb5[0]; b[1] = log[j].rgb5[1]; b[2] = log[j].rgb5[2];
+            }
+            call += n;
+            end_of_sweep();
+        }
+        if (calls) {
+            char m[200];
+            snprintf(m, sizeof m, "Ran %u calls in %u launch sets: %u changed the palette, %llu of %llu candidates scored were of calls that took effect", total.calls, total.windows, total.accepted,
+                     (unsigned long long)total.useful, (unsigned long long)total.scored);
+            log_info(m);
+        }
+    } else
+    for (uint32_t call = 0; call < calls; call++) {
+        uint32_t p = palette, ix = index, ch = channel, method = 0;
+        snesimage_schedule_next(count, size, nes, &palette, &index, &channel, &step, &method);
+        snesimage_get_palette_rgb5(ctx, before.data());
+        double error = 0.0; uint8_t best[3];
+        const int32_t rc = group ? snesimage_group_step(group, method, p, ix, ch, seed, call, method == SNES_METHOD_RANDOM ? ncand : 0, &error, best)
+                                 : snesimage_step(ctx, method, p, ix, ch, seed, call, method == SNES_METHOD_RANDOM ? ncand : 0, &error, best);
+        if (rc != 0) die(std::string("Unable to optimize palette: ") + snesimage_last_error());
+        report(p, ix, &before[3 * ((size_t)p * size + ix)], best, error);
+        end_of_sweep();
     }
     log_info("Writing output to " + target); // src/lib.rs:1000-1002
     int64_t need = snesimage_as_json(ctx, nullptr, 0);

@@ -194,3 +194,29 @@ def test_cli_devices_flag_gives_the_single_device_result(tmp_path):
     r2 = run(args[0], str(b), *args[1:], "--devices", "0")
     assert r1.returncode == 0 and r2.returncode == 0, r2.stdout + r2.stderr
     assert "Sharding candidates over 1 device(s)" in r2.stdout and a.read_text() == b.read_text()
+
+
+def _log_lines(stdout):
+    """The driver's log without its timestamps and without the launch-set summary (which differs between window sizes)."""
+    return [l.split("]", 1)[1] for l in stdout.splitlines() if "] Ran " not in l and "] Writing output" not in l and "]" in l]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,extra", [("traj_rgb_2x3", []), ("traj_dither_2x3", ["-d"])])
+def test_cli_default_loop_is_speculative_and_matches_the_oracle_trajectory(tmp_path, name, extra):
+    """With the reference's 64 candidates per call the driver runs snesimage_run_slots (several calls per launch set): the
+    JSON of 216 calls equals the oracle's call-by-call trajectory (tests/golden/trajectories.json) byte for byte, and the
+    log — every colour change, every error — equals the log of --window 1."""
+    import hashlib
+    case = next(c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "trajectories.json")))["cases"] if c["name"] == name)
+    assert case["first_call"] == 0
+    a, b = tmp_path / "a.json", tmp_path / "b.json"
+    args = ["synth:%d" % case["seed"], "-c", str(case["count"]), "-s", str(case["size"]), "--calls", str(len(case["calls"])), "--seed", str(case["cand_seed"]), *extra]
+    r1 = run(args[0], str(a), *args[1:])
+    r2 = run(args[0], str(b), *args[1:], "--window", "1")
+    assert r1.returncode == 0 and r2.returncode == 0, r1.stdout + r1.stderr + r2.stdout + r2.stderr
+    assert hashlib.sha256(a.read_bytes()).hexdigest() == case["json_sha"]
+    assert a.read_bytes() == b.read_bytes()
+    assert "launch sets" in r1.stdout and _log_lines(r1.stdout) == _log_lines(r2.stdout)
+    changes = [l for l in r1.stdout.splitlines() if "Setting color" in l]
+    assert len(changes) == case["accepted"]
