@@ -126,7 +126,8 @@ int32_t snesimage_slots_reserve(snesimage_ctx *ctx, uint32_t n_slots);
 /* The two phases of one window, for sharding its calls over GPUs (call j of the window -> rank j % shard_count: its own base
  * image, its own candidates).  Phase 1 takes at most n_slots calls from the given scheduler state — fewer where the method
  * changes, all calls of a window having the same number of candidates (*stride) — and writes errors[j * stride + k]
- * (device, n_slots * 64 doubles; +inf for calls of other ranks; NULL = the context's own vector, single rank only).  The
+ * (device, n_slots * 64 doubles; +inf for calls of other ranks; NULL = the context's own vector, single rank only);
+ * n_slots is capped at SNES_WINDOW_MAX * shard_count (and 1024).  The
  * caller min-all-reduces the first *n_taken * *stride doubles, then phase 2 commits identically on every rank: *consumed
  * calls took effect, *accepted = the last of them changed the palette; log (host, optional): *n_taken records. */
 int32_t snesimage_slots_begin(snesimage_ctx *ctx, uint32_t n_slots, uint64_t seed, uint64_t first_step_id, uint32_t palette,

@@ -20,7 +20,10 @@ for d in dirs:
             name = row["Kernel_Name"].split("(")[0]
             a = acc[name][row["Counter_Name"]]
             a[0] += float(row["Counter_Value"]); a[1] += 1
-res = {"command": cmd, "candidates_per_launch": cpl, "note": "PMC collection serialises kernels: every figure is for the kernel running alone", "kernels": {}}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from snesimage_amd import _ffi  # noqa: E402
+version = _ffi.load().snesimage_version().decode()
+res = {"command": cmd, "candidates_per_launch": cpl, "library": version, "source_hash": version.split("src:")[1].strip() if "src:" in version else None, "note": "PMC collection serialises kernels: every figure is for the kernel running alone", "kernels": {}}
 for k, cs in sorted(acc.items()):
     e = {c: {"sum": v[0], "mean": v[0] / v[1], "dispatches": v[1]} for c, v in cs.items()}
     if "FETCH_SIZE" in e and "WRITE_SIZE" in e:

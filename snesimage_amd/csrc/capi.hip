@@ -808,7 +808,10 @@ int32_t commit(snesimage_ctx *c, const double *d_errors, uint32_t n, uint32_t me
 extern "C" {
 
 const char *snesimage_last_error(void) { return g_err.c_str(); }
-const char *snesimage_version(void) { return "snesimage_hip 0.1.0 (gfx950)"; }
+#ifndef SNES_SRC_HASH
+#define SNES_SRC_HASH "unknown"
+#endif
+const char *snesimage_version(void) { return "snesimage_hip 0.2.0 (gfx950) src:" SNES_SRC_HASH; } // src: hash of the library's sources (csrc/Makefile)
 
 int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t sub_count, uint32_t sub_size, uint32_t flags, int32_t device, snesimage_ctx **out) {
     if (!rgba || !out) return fail(SNES_ERR_ARG, "null pointer");

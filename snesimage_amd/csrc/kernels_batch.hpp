@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void kb_commit(const BatchArgs *__restrict__ A
 // one-call-at-a-time loop, whatever K.
 struct WindowSlot { int method, n, slot, channel, nes, pad; unsigned long long key; };
 struct WindowResult { int consumed, accepted; };
-constexpr int kMaxWindow = 256;
+constexpr int kMaxWindow = 1024; // calls per window over all ranks
 
 // The candidate lists of all K calls (every rank generates all of them: the commit needs the winner's colour wherever it
 // was scored) and the error vector preset to +inf (a rank fills in the calls it owns; the others arrive by min-all-reduce).

@@ -61,3 +61,103 @@ def sharded_step(scorer, method, palette, index, channel, seed, step_id, n_total
             dist.all_reduce(errors, op=dist.ReduceOp.MIN, group=group)
     scorer.commit(errors)
     return errors
+
+
+# ---- slot windows: the reference's own loop (64 / 32 / 56 candidates per call), calls dealt to the ranks -----------------
+#
+# `sharded_step` splits ONE call's candidates; its base image is computed by every rank.  A *window* (DESIGN.md,
+# snesimage_run_slots) holds K consecutive calls of the schedule, all scored against the same palette: call j of the window
+# belongs to rank j % world — its own base image, its own candidates — and the only exchange is ONE min-all-reduce over the
+# window's K x n error vector.  Every rank then applies the calls' decisions in order and stops behind the first call that
+# changed the palette (lib.rs:216-219: strict <), so the ranks stay bit-identical without a broadcast and the trajectory is
+# the reference's, call for call.
+#
+# A *window scorer* has
+#     slots_begin(n_slots, seed, first_step_id, state, rank, world) -> (errors, taken, stride): 1-D float64 tensor of at
+#         least taken * stride entries, this rank's calls filled in and +inf elsewhere (fewer calls than asked for where the
+#         method changes: all calls of a window have `stride` candidates), and
+#     slots_commit(errors, taken) -> (consumed, accepted, log): calls that took effect, whether the last one changed the
+#         palette, and per consumed call (error, best_k, rgb5, changed).
+
+
+def schedule_advance(sub_count, sub_size, state, n, nes=False):
+    """Scheduler state (palette, index, channel, step) after n more calls (lib.rs:917-932)."""
+    import ctypes as C
+
+    from . import _ffi
+    L = _ffi.load()
+    p, i, ch, st, m = (C.c_uint32(int(v)) for v in (*state, 0))
+    for _ in range(n):
+        L.snesimage_schedule_next(sub_count, sub_size, int(nes), C.byref(p), C.byref(i), C.byref(ch), C.byref(st), C.byref(m))
+    return (p.value, i.value, ch.value, st.value)
+
+
+class HipWindowScorer(HipShardScorer):
+    """Slot windows over libsnesimage_hip.so; the error vector lives in HBM."""
+
+    MAX_WINDOW = 1024  # calls per window over all ranks (the library takes at most SNES_WINDOW_MAX, default 64, per rank)
+
+    def __init__(self, image, device):
+        super().__init__(image, device)
+        self._wbuf = torch.empty(self.MAX_WINDOW * 64, dtype=torch.float64, device=device)
+
+    def slots_begin(self, n_slots, seed, first_step_id, state, rank, world):
+        taken, stride = self.image.slots_begin(min(n_slots, self.MAX_WINDOW), seed, first_step_id, state, 0, rank, world,
+                                               self._wbuf.data_ptr())
+        return self._wbuf, taken, stride
+
+    def slots_commit(self, errors, taken):
+        return self.image.slots_commit(errors.data_ptr(), taken)
+
+
+class WindowPolicy:
+    """Calls per window: twice as many after a window that accepted nothing, else about the run of calls the last one got
+    through (the library's own rule in snesimage_run_slots), at least `lo` per rank."""
+
+    def __init__(self, world=1, lo=8, hi=64):
+        self.lo, self.hi = lo * world, hi * world
+        self.k = self.lo
+
+    def update(self, taken, consumed, accepted):
+        if not accepted:
+            if taken >= self.k:
+                self.k = min(self.hi, self.k * 2)
+        else:
+            a = self.lo
+            while a < consumed:
+                a *= 2
+            self.k = min(self.hi, a)
+
+
+def sharded_run_slots(scorer, sub_count, sub_size, n_calls, seed=1, first_step_id=0, state=(0, 0, 0, 0), window=0, group=None, nes=False):
+    """The reference's loop for n_calls calls, the calls of every window dealt to the ranks of `group`.
+    Returns (log, state, stats) like OptimizedImage.run_slots."""
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    policy = WindowPolicy(world)
+    done, log = 0, []
+    stats = {"calls": 0, "accepted": 0, "windows": 0, "scored": 0, "useful": 0}
+    while done < n_calls:
+        k = min(window or policy.k, n_calls - done)
+        errors, taken, stride = scorer.slots_begin(k, seed, first_step_id + done, state, rank, world)
+        if world > 1 or (dist.is_available() and dist.is_initialized()):
+            vec = errors[: taken * stride]  # contiguous view: reduced in place
+            stream = getattr(scorer, "stream", None)
+            if stream is not None:
+                with torch.cuda.stream(stream):
+                    dist.all_reduce(vec, op=dist.ReduceOp.MIN, group=group)
+            else:
+                dist.all_reduce(vec, op=dist.ReduceOp.MIN, group=group)
+        consumed, accepted, wlog = scorer.slots_commit(errors, taken)
+        log += wlog or []
+        state = schedule_advance(sub_count, sub_size, state, consumed, nes)
+        done += consumed
+        stats["calls"] += consumed
+        stats["accepted"] += accepted
+        stats["windows"] += 1
+        stats["scored"] += taken * stride
+        stats["useful"] += consumed * stride
+        policy.update(taken, consumed, accepted)
+    return log, state, stats
