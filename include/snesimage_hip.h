@@ -151,6 +151,14 @@ int32_t snesimage_group_step(snesimage_group *group, uint32_t method, uint32_t p
                              uint32_t channel, uint64_t seed, uint64_t step_id, uint32_t n_total,
                              double *best_error, uint8_t *best_rgb5 /*3*/);
 
+/* snesimage_run_slots over a group: the calls of every window are dealt to the members (call j -> member j % N), one grouped
+ * RCCL all-reduce(min) over the window's error vector, identical in-order commit on every member.  Same arguments, same
+ * trajectory (lib.rs:888-933), bit-identical palettes on all devices.  Every member must be in the state
+ * snesimage_group_create asks for. */
+int32_t snesimage_group_run_slots(snesimage_group *group, uint32_t n_calls, uint64_t seed, uint64_t first_step_id,
+                                  uint32_t *palette, uint32_t *index, uint32_t *channel, uint32_t *step, uint32_t window,
+                                  snesimage_call_result *log, snesimage_run_stats *stats);
+
 /* Throughput mode — many independent images on one device, one launch per stage of an optimizer call
  * for all of them (the reference runs one image per process: `run()` lib.rs:830-1024 once per file).
  * A batch borrows its contexts (same device, image size, palette geometry, chunk and distance — RGB redmean or

@@ -194,6 +194,12 @@ def test_cli_devices_flag_gives_the_single_device_result(tmp_path):
     r2 = run(args[0], str(b), *args[1:], "--devices", "0")
     assert r1.returncode == 0 and r2.returncode == 0, r2.stdout + r2.stderr
     assert "Sharding candidates over 1 device(s)" in r2.stdout and a.read_text() == b.read_text()
+    # the reference's 64 candidates per call: slot windows, sharded by calls through snesimage_group_run_slots
+    args = ["synth:1592590340", "-c", "4", "-s", "7", "--calls", "40", "--seed", "9"]
+    r1 = run(args[0], str(a), *args[1:])
+    r2 = run(args[0], str(b), *args[1:], "--devices", "0")
+    assert r1.returncode == 0 and r2.returncode == 0, r2.stdout + r2.stderr
+    assert "launch sets" in r2.stdout and a.read_text() == b.read_text()
 
 
 def _log_lines(stdout):
