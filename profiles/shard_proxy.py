@@ -7,6 +7,10 @@ is timed for G in {1, 2, 4, 8} at a fixed total number of candidates per call.  
 bounds the compute side of the strong-scaling efficiency from above: it contains everything a rank does itself (the
 replicated work on B and the pack, its share of the candidates, the commit) and leaves out only the RCCL min-all-reduce
 of n doubles (latency-bound, ~10-20 us over xGMI).  Prints one JSON object.
+
+--windows K1,K2,...: the same for the slot windows of the reference's loop (snesimage_slots_begin / _commit): a window of K
+calls x 64 candidates, its calls dealt to G ranks in blocks of consecutive calls (own base images, own candidates).  Rank 0's share is
+timed; a rank takes at most 64 calls of a window, so a single GPU works through K calls as K/64 windows in a row.
 """
 import argparse
 import json
@@ -23,6 +27,8 @@ def main():
     ap.add_argument("--totals", default="64,4096")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--config", choices=["rgb", "perceptual", "dither"], default="rgb")
+    ap.add_argument("--windows", default="", help="calls per window (64 candidates each) for the slot-window proxy, e.g. 64,128,256,512")
+    ap.add_argument("--converge", type=int, default=20, help="--windows: sweeps of 4,096-candidate calls first (windows are for the regime where calls rarely accept)")
     args = ap.parse_args()
     import torch
 
@@ -56,6 +62,41 @@ def main():
             t1 = t if G == 1 else t1
             out["rows"].append({"candidates_per_call": total, "G": G, "own_candidates": (total + G - 1) // G, "ms_per_call": t * 1e3,
                                 "efficiency_bound": t1 / (G * t)})
+    if args.windows:
+        sweep = S.schedule(8, 15, 120)
+        for j in range(120 * args.converge):
+            _, p, idx, _, _ = sweep[j % 120]
+            img.step_async(S.METHOD_RANDOM, p, idx, 0, 5, 10 ** 7 + j, 4096)
+        img.sync()
+        img.slots_reserve(64)
+        wbuf = torch.empty(1024 * 64, dtype=torch.float64, device=dev)
+        out["window_rows"] = []
+        for K in [int(t) for t in args.windows.split(",")]:  # (K <= 480: the random calls of steps 0..3; a window ends where the method changes)
+            t1 = None
+            for G in (1, 2, 4, 8):
+                per_window = min(K, 64 * G)  # calls of one window over all ranks
+                reps = (K + per_window - 1) // per_window  # windows a rank works through for K calls in all (the last one may be shorter)
+
+                states = [S.schedule(8, 15, w * per_window + 1)[-1][1:] for w in range(reps)]  # every G walks the same K calls of the schedule
+
+                def run_w(n, rank):
+                    for i in range(n):
+                        for w in range(reps):
+                            taken, stride = img.slots_begin(min(per_window, K - w * per_window), 1, 10 ** 6 + i * 2048 + w * per_window, states[w], 0, rank, G, wbuf.data_ptr())
+                            img.slots_commit(wbuf.data_ptr(), 0)
+                per_rank = []
+                for rank in range(G):  # the calls differ in cost (subpalettes differ in size): a window takes as long as its slowest rank
+                    run_w(2, rank)
+                    torch.cuda.synchronize()
+                    n = max(4, 2048 // K)
+                    t0 = time.perf_counter()
+                    run_w(n, rank)
+                    torch.cuda.synchronize()
+                    per_rank.append((time.perf_counter() - t0) / n)
+                t = max(per_rank)
+                t1 = t if G == 1 else t1
+                out["window_rows"].append({"calls_per_window_total": K, "G": G, "own_calls_per_window": (per_window + G - 1) // G, "windows_in_a_row": reps,
+                                           "ms_for_K_calls_slowest_rank": t * 1e3, "ms_per_rank": [x * 1e3 for x in per_rank], "efficiency_bound": t1 / (G * t)})
     print(json.dumps(out))
     img.close()
 

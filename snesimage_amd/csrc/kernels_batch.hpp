@@ -100,7 +100,7 @@ __global__ void kw_gen_candidates(const WindowSlot *__restrict__ S, const uint8_
     gen_candidates_body(w.method, w.n, w.key, colors, w.slot, w.channel, cand + 3 * (size_t)blockIdx.y * stride, 0, 1, nullptr, nullptr);
 }
 
-// In-order commit: per call the first-lowest error (one wave per call, lexicographic (error, index) minimum: what the
+// In-order commit: per call the first-lowest error (sixteen lanes per call, lexicographic (error, index) minimum: what the
 // ascending strict-< scan of lib.rs:216-219 ends on), then one thread applies the calls' decisions in sequence and stops
 // behind the first call that changed the state (a candidate accepted; for the NES method, which always takes its table
 // argmin, a colour that differs from the current one).  log[j] = what snesimage_last_step would report after call j.
@@ -109,25 +109,54 @@ __global__ __launch_bounds__(1024) void kw_commit(const WindowSlot *__restrict__
     if (*dead) { if (threadIdx.x == 0) { res->consumed = 0; res->accepted = 0; } return; } // voided by an earlier window's commit: nothing of this one happened
     __shared__ double s_e[kMaxWindow];
     __shared__ int s_k[kMaxWindow];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int j = w; j < K; j += 16) {
+    const int l16 = threadIdx.x & 15, q = threadIdx.x >> 4; // sixteen lanes per call: 64 calls at a time (the loads' latency is what this loop costs)
+    for (int j = q; j < K; j += 64) {
         const int n = S[j].n;
         double be = __longlong_as_double(0x7ff0000000000000ll); int bk = 0x7fffffff;
-        for (int k = lane; k < n; k += 64) { const double e = errors[(size_t)j * stride + k]; if (e < be) { be = e; bk = k; } } // NaN never wins, as in the reference
+        for (int k = l16; k < n; k += 16) { const double e = errors[(size_t)j * stride + k]; if (e < be) { be = e; bk = k; } } // NaN never wins, as in the reference
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
+        for (int o = 8; o > 0; o >>= 1) {
             const double e2 = __shfl_xor(be, o); const int k2 = __shfl_xor(bk, o);
             if (e2 < be || (e2 == be && k2 < bk)) { be = e2; bk = k2; }
         }
-        if (lane == 0) { s_e[j] = be; s_k[j] = bk; }
+        if (l16 == 0) { s_e[j] = be; s_k[j] = bk; }
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
     int consumed = 0, accepted = 0;
-    for (int j = 0; j < K && !accepted; j++) {
-        commit_decide(s_e[j], s_k[j], cand + 3 * (size_t)j * stride, colors, S[j].slot, S[j].nes, inc_err, log + j, T);
-        consumed = j + 1;
-        accepted = S[j].nes ? (log[j].changed ? 1 : 0) : (log[j].best_k >= 0 ? 1 : 0);
+    if (K > 0 && !S[0].nes) {
+        // Every call up to the first acceptance is measured against the same incumbent error, so which call accepts first is a
+        // parallel minimum; the calls before it report "nothing accepted" (incumbent error, the slot's colour as it stands) —
+        // written by all threads — and only the accepting call is decided by one thread (a sequential walk over the calls, a
+        // few dependent global accesses each, cost ~1.2 us per call: 0.6 ms for the 512 calls of an 8-GPU window)
+        __shared__ int s_first;
+        if (threadIdx.x == 0) s_first = K;
+        __syncthreads();
+        const double inc = *inc_err;
+        for (int j = threadIdx.x; j < K; j += 1024) if (s_k[j] != 0x7fffffff && s_e[j] < inc) atomicMin(&s_first, j);
+        __syncthreads();
+        const int first = s_first;
+        for (int j = threadIdx.x; j < first; j += 1024) {
+            const int slot = S[j].slot;
+            StepResult r; r.error = inc; r.best_k = -1; r.rgb5[0] = colors[3 * slot]; r.rgb5[1] = colors[3 * slot + 1]; r.rgb5[2] = colors[3 * slot + 2]; r.changed = 0;
+            log[j] = r;
+        }
+        if (threadIdx.x != 0) return;
+        consumed = first;
+        if (first < K) {
+            commit_decide(s_e[first], s_k[first], cand + 3 * (size_t)first * stride, colors, S[first].slot, 0, inc_err, log + first, T);
+            consumed = first + 1; accepted = 1;
+        } else if (K > 0) { // (this thread's own copy of the last record: the one in log[] may be another thread's store)
+            const int slot = S[K - 1].slot;
+            StepResult r; r.error = inc; r.best_k = -1; r.rgb5[0] = colors[3 * slot]; r.rgb5[1] = colors[3 * slot + 1]; r.rgb5[2] = colors[3 * slot + 2]; r.changed = 0;
+            log[K - 1] = r;
+        }
+    } else {
+        if (threadIdx.x != 0) return;
+        for (int j = 0; j < K && !accepted; j++) { // the NES method always takes its table argmin and moves the incumbent error with it: in sequence
+            commit_decide(s_e[j], s_k[j], cand + 3 * (size_t)j * stride, colors, S[j].slot, S[j].nes, inc_err, log + j, T);
+            consumed = j + 1;
+            accepted = log[j].changed ? 1 : 0;
+        }
     }
     res->consumed = consumed; res->accepted = accepted;
     if (accepted) *dead = 1; // windows already enqueued behind this one were built for the old palette
@@ -135,17 +164,17 @@ __global__ __launch_bounds__(1024) void kw_commit(const WindowSlot *__restrict__
 }
 
 // --dither: the committed state's palette_map (lib.rs:237 re-runs optimize() on the winner's palette).  The winner's own
-// resumed run IS that map: adopted if its call was scored on this rank (call j -> rank j % count, slot context j / count);
+// resumed run IS that map: adopted if its call was scored on this rank (calls [j_first, j_first + own), slot context j - j_first);
 // *skip = 1 then, and also when nothing was accepted (the stored map stands); 0 = the caller has to dither again.
-__global__ __launch_bounds__(1024) void kw_take_map(const BatchArgs *__restrict__ A, int rank, int count, const WindowResult *__restrict__ res, const StepResult *__restrict__ log,
+__global__ __launch_bounds__(1024) void kw_take_map(const BatchArgs *__restrict__ A, int j_first, int own, const WindowResult *__restrict__ res, const StepResult *__restrict__ log,
                                                    uint8_t *__restrict__ map, int npx, int *__restrict__ skip) {
     const int consumed = res->consumed, accepted = res->accepted;
     int have = 1;
     if (accepted) {
         const int j = consumed - 1, k = log[j].best_k;
-        have = (j % count == rank) ? 1 : 0;
+        have = (j >= j_first && j < j_first + own) ? 1 : 0;
         if (have) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(A[j / count].Pc.maps + (size_t)k * npx);
+            const uint4 *src = reinterpret_cast<const uint4 *>(A[j - j_first].Pc.maps + (size_t)k * npx);
             uint4 *dst = reinterpret_cast<uint4 *>(map);
             for (int i = threadIdx.x; i < npx / 16; i += 1024) dst[i] = src[i];
         }
