@@ -36,6 +36,10 @@ ALGO_BYTES_PER_CANDIDATE = 263408  # 262,144 source RGBA8 + 1,024
 SSIM2_DENSE_BYTES_PER_CANDIDATE = 3408368
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0  # G wave64 instructions/s: 1,024 SIMD-32s, 2 cycles per binary32 wave instruction, 2.4 GHz
+# What the chip sustains on the V pass's own mix — measured, not nominal (profiles/micro/valu_rate_mi355x.txt: per wave-instruction
+# and SIMD with two or more waves resident, v_fma_f32 1.35 ns, v_add_f32 1.16 ns, v_fma_f64 2.3-2.4 ns, v_add/mul_f64 1.85-2.0 ns,
+# v_cvt_f64_f32 1.8 ns): ~165 binary32 (1.3 ns) and ~80 binary64 (2.0 ns) instructions per group iteration
+VALU_SUSTAINED_GINSTR = 1024 * 245.0 / (165 * 1.3 + 80 * 2.0)
 
 
 def lib_version():
@@ -417,6 +421,8 @@ def main():
                 rate = per_cand * per_launch / (dom_ms * 1e-3)
                 valu = {"kernel": dom, "wave_instructions_per_candidate": per_cand, "achieved_Ginstr_s": rate / 1e9,
                         "peak_Ginstr_s": VALU_PEAK_GINSTR, "frac": rate / 1e9 / VALU_PEAK_GINSTR,
+                        "sustained_peak_Ginstr_s": VALU_SUSTAINED_GINSTR, "frac_of_sustained": rate / 1e9 / VALU_SUSTAINED_GINSTR,
+                        "sustained_peak_source": "profiles/micro/valu_rate_mi355x.txt: measured issue rates on the kernel's binary32 / binary64 mix",
                         "VALUBusy_percent": k.get("VALUBusy", {}).get("mean"), "source": pmc_path}
         except (OSError, KeyError, ValueError, ZeroDivisionError):
             pass

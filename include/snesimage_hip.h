@@ -180,7 +180,9 @@ int32_t snesimage_batch_sync(snesimage_batch *batch);
  * attempt is made to reassign tiles dynamically if it could improve the overall result").  Every tile with an opaque pixel
  * moves to the subpalette with the strictly smallest cost, cost(p) = sum over the tile's opaque pixels (raster order) of the
  * distance optimize() minimises (lib.rs:1080-1100) to the nearest entry of subpalette p, in binary64; ties keep the current
- * subpalette, then the lower index.  Palettes are kept; optimize() re-runs if a tile moved.  *moved = tiles moved. */
+ * subpalette, then the lower index.  Palettes are kept; optimize() re-runs if a tile moved.  *moved = tiles moved.
+ * Refused (SNES_ERR_STATE) between the two phases of a split-phase step.  On the members of a group call it on every
+ * member (the result is deterministic: the replicas stay identical), never on one alone. */
 int32_t snesimage_reassign_tiles(snesimage_ctx *ctx, uint32_t *moved);
 
 /* State access (the reference mutates these fields directly: lib.rs:1015 and the GUI). */

@@ -10,6 +10,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -90,9 +91,12 @@ template <typename T> void dfree(T *&p) { if (p) { (void)hipFree(p); p = nullptr
 
 // Every workspace allocation goes through dmalloc so that tests can make the n-th one fail (snesimage_debug_fail_alloc):
 // the grow-on-demand allocators must leave the context usable after a failed grow.
-int g_fail_alloc_in = -1; // -1: off; otherwise the number of allocations that still succeed
+std::atomic<int> g_fail_alloc_in{-1}; // -1: off; otherwise the number of allocations that still succeed (host threads initialising a batch of images allocate side by side)
 template <typename T> hipError_t dmalloc(T **p, size_t bytes) {
-    if (g_fail_alloc_in >= 0) { if (g_fail_alloc_in == 0) { g_fail_alloc_in = -1; *p = nullptr; return hipErrorOutOfMemory; } g_fail_alloc_in--; }
+    int left = g_fail_alloc_in.load(std::memory_order_relaxed);
+    while (left >= 0) { // claim one of the remaining successes, or be the allocation that fails
+        if (g_fail_alloc_in.compare_exchange_weak(left, left - 1, std::memory_order_relaxed)) { if (left == 0) { *p = nullptr; return hipErrorOutOfMemory; } break; }
+    }
     return hipMalloc(p, bytes);
 }
 
@@ -166,11 +170,14 @@ struct snesimage_ctx {
     uint8_t *d_dummy_cand = nullptr;
     // k-means workspace
     KmeansWork km{};
+    // snesimage_reassign_tiles: cost per (tile, subpalette), tiles with an opaque pixel, tiles moved (kept: hipMalloc / hipFree per call synchronise the device)
+    double *d_tile_cost = nullptr; int *d_tile_any = nullptr; unsigned int *d_tile_moved = nullptr;
 
     struct snesimage_batch *owner = nullptr; // set while the context is lent to a batch (batch_host.inc)
     struct snesimage_group *group = nullptr; // set while the context is a member of a group (group_host.inc)
     hipEvent_t ev_own = nullptr;             // marks the end of the work this context queued on its own stream (for its batch)
     struct snesimage_window *win = nullptr;  // slot windows of snesimage_run_slots (window_host.inc), created on first use
+    bool win_pend = false;                   // snesimage_slots_begin without its snesimage_slots_commit yet
     bool pack_borrowed = false;              // a slot context of a --dither window: pack and subpalette planes are the parent's
 
     // cache keys
@@ -590,8 +597,8 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
         hipLaunchKernelGGL(k_sparse_scan_lab, dim3(nc), dim3(256), 0, stream, P);
     } else hipLaunchKernelGGL(k_sparse_scan, dim3((nc + 15) / 16), dim3(1024), 0, stream, P);
     hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P, 0);
-    if (c->timing) HIPCHK(hipEventRecord(tr.ev[1], stream));
     if (sp.side) HIPCHK(hipStreamWaitEvent(stream, sp.ev_base_h, 0)); // B's H-pass checkpoints (a short list gets here before B's sweep is through)
+    if (c->timing) HIPCHK(hipEventRecord(tr.ev[1], stream)); // ev[1]..ev[2]: the candidates' H pass alone (the wait for B's sweep is before it)
     { size_t gx = ((size_t)nc * (G.sh[0] / 4) * 3 + 15) / 16; if (gx > sp.hgrid) gx = sp.hgrid; // grid-stride over the item quads
       if (nc <= sp.h2q_max) { // a short list: the H pass with a quad of lanes per row (a third of the chain, four times the waves)
           size_t gq = ((size_t)nc * (G.sh[0] / 4) * 3 + 3) / 4; if (gq > sp.hgrid) gq = sp.hgrid;
@@ -599,8 +606,8 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
       } else
       hipLaunchKernelGGL(k_sparse_h2, dim3((unsigned)gx, (unsigned)(P.s_first * kColBuckets)), dim3(64), h2_lds(c), stream, P);
       if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((gx + 7) / 8), (unsigned)((G.nscales - P.s_first) * kColBuckets)), dim3(64), 0, stream, P); }
-    if (sp.side || stream != c->stream) HIPCHK(hipStreamWaitEvent(stream, sp.side ? sp.ev_base_done : c->ev_ready, 0)); // checkpoints and H output of B
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[2], stream));
+    if (sp.side || stream != c->stream) HIPCHK(hipStreamWaitEvent(stream, sp.side ? sp.ev_base_done : c->ev_ready, 0)); // checkpoints and H output of B
     if (c->sp.lpt && nc > 512) { // (a short list's blocks are all resident at once: their order is immaterial)
         hipLaunchKernelGGL(k_sparse_order, dim3(1), dim3(1024), 0, stream, P, sp.order + P.k0); P.order = sp.order + P.k0;
     }
@@ -932,7 +939,7 @@ void snesimage_destroy(snesimage_ctx *c) {
     dfree(c->d_packC4); dfree(c->d_packR4); dfree(c->d_subC4); dfree(c->d_subR4); dfree(c->d_mapsC4); dfree(c->d_mapsR4); dfree(c->d_img1C4); dfree(c->d_mu1R4); dfree(c->d_sd1R4); dfree(c->d_r1); dfree(c->d_r1R4); dfree(c->d_a1); dfree(c->d_a1R4);
     dfree(c->d_orig); dfree(c->d_tile_pal); dfree(c->d_colors); dfree(c->d_map); dfree(c->d_pack); dfree(c->d_packT); dfree(c->d_eotf); dfree(c->d_lab_eotf);
     dfree(c->d_pal_rgb8); dfree(c->d_pal_lin); dfree(c->d_pal_xyb); dfree(c->d_pal_lab); dfree(c->d_lin0); dfree(c->d_img1); dfree(c->d_img1T); dfree(c->d_mu1); dfree(c->d_sd1);
-    dfree(c->d_bestmaps_all); dfree(c->d_bestrecs_all); dfree(c->d_skip); dfree(c->d_rplist); dfree(c->d_rcount);
+    dfree(c->d_bestmaps_all); dfree(c->d_bestrecs_all); dfree(c->d_skip); dfree(c->d_rplist); dfree(c->d_rcount); dfree(c->d_tile_cost); dfree(c->d_tile_any); dfree(c->d_tile_moved);
     dfree(c->d_labpx); dfree(c->d_labpxT); dfree(c->d_work); dfree(c->d_cand_tab); dfree(c->d_cand_lab); dfree(c->d_part); dfree(c->d_maps); dfree(c->d_mapsT);
     dfree(c->d_cand); dfree(c->d_cand_sel); dfree(c->d_errs); dfree(c->d_errs_sel); dfree(c->d_inc_err); dfree(c->d_last); dfree(c->d_scratch_err); dfree(c->d_dummy_cand);
     for (auto &L : c->extra) { if (L.stream) (void)hipStreamSynchronize(L.stream); dfree(L.d_mapsC4); dfree(L.d_mapsR4); dfree(L.d_work); dfree(L.d_cand_tab); dfree(L.d_cand_lab); dfree(L.d_part); dfree(L.d_maps); dfree(L.d_mapsT); if (L.done) (void)hipEventDestroy(L.done); if (L.stream) (void)hipStreamDestroy(L.stream); }
@@ -1259,30 +1266,25 @@ int32_t snesimage_recalculate_palettes(snesimage_ctx *c) {
 // Not in the reference (TODO.md:36-37 names it as missing): move every tile to the subpalette that reproduces it best.
 int32_t snesimage_reassign_tiles(snesimage_ctx *c, uint32_t *moved_out) {
     if (!c) return fail(SNES_ERR_ARG, "null context");
+    if (c->pend || c->win_pend) return fail(SNES_ERR_STATE, "a split-phase step is pending: commit it first (its candidates were scored for the current tile assignment)");
     CHECK(set_device(c));
     CHECK(ensure_map(c)); // an optimize() still owed belongs to the state before this change
     CHECK(ensure_tables(c));
     if (c->perceptual) CHECK(ensure_source(c));
     const int ntile = (int)((c->W / 8) * (c->H / 8)), n = ntile * (int)c->sub_count;
-    double *d_cost = nullptr; int *d_any = nullptr; unsigned int *d_moved = nullptr;
-    auto cleanup = [&]() { if (d_cost) (void)hipFree(d_cost); if (d_any) (void)hipFree(d_any); if (d_moved) (void)hipFree(d_moved); };
+    if (!c->d_tile_cost) {
+        HIPCHK(dmalloc(&c->d_tile_cost, sizeof(double) * n));
+        HIPCHK(dmalloc(&c->d_tile_any, sizeof(int) * ntile));
+        HIPCHK(dmalloc(&c->d_tile_moved, sizeof(unsigned int)));
+    }
     unsigned int moved = 0;
-    auto body = [&]() -> int32_t {
-        HIPCHK(hipMalloc(&d_cost, sizeof(double) * n));
-        HIPCHK(hipMalloc(&d_any, sizeof(int) * ntile));
-        HIPCHK(hipMalloc(&d_moved, sizeof(unsigned int)));
-        HIPCHK(hipMemsetAsync(d_moved, 0, sizeof(unsigned int), c->stream));
-        hipLaunchKernelGGL(k_tile_costs, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_orig, c->d_pal_rgb8, c->d_pal_lab, c->d_labpx, (int)c->W, (int)c->H, (int)c->sub_count,
-                           (int)c->sub_size, c->perceptual ? 1 : 0, d_cost, d_any);
-        hipLaunchKernelGGL(k_tile_move, dim3((ntile + 255) / 256), dim3(256), 0, c->stream, d_cost, d_any, ntile, (int)c->sub_count, c->d_tile_pal, d_moved);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&moved, d_moved, sizeof(moved), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        return SNES_OK;
-    };
-    const int32_t rc = body();
-    cleanup();
-    if (rc != SNES_OK) return rc;
+    HIPCHK(hipMemsetAsync(c->d_tile_moved, 0, sizeof(unsigned int), c->stream));
+    hipLaunchKernelGGL(k_tile_costs, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_orig, c->d_pal_rgb8, c->d_pal_lab, c->d_labpx, (int)c->W, (int)c->H, (int)c->sub_count,
+                       (int)c->sub_size, c->perceptual ? 1 : 0, c->d_tile_cost, c->d_tile_any);
+    hipLaunchKernelGGL(k_tile_move, dim3((ntile + 255) / 256), dim3(256), 0, c->stream, c->d_tile_cost, c->d_tile_any, ntile, (int)c->sub_count, c->d_tile_pal, c->d_tile_moved);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&moved, c->d_tile_moved, sizeof(moved), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     if (moved) { // as after snesimage_set_tile_palettes, then optimize() (the palettes are kept)
         c->pack_valid = false; c->inc_valid = false; c->map_synced = false;
         CHECK(do_optimize(c));
@@ -1311,7 +1313,7 @@ int32_t snesimage_timing_read(snesimage_ctx *c, double *ms3, uint64_t *launches,
 }
 
 // test hook: the (n+1)-th workspace allocation from now on fails with hipErrorOutOfMemory (n < 0: off)
-void snesimage_debug_fail_alloc(int32_t n) { g_fail_alloc_in = n; }
+void snesimage_debug_fail_alloc(int32_t n) { g_fail_alloc_in.store(n); }
 
 int32_t snesimage_debug_math(int32_t device, int32_t op, const float *x, const float *y, uint32_t n, float *out) {
     if (!x || !out || n == 0) return fail(SNES_ERR_ARG, "bad arguments");

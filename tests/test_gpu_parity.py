@@ -590,6 +590,39 @@ def test_sparse_path_equals_dense_path(S, O, seed, variant, perceptual, monkeypa
     sparse.close()
 
 
+@pytest.mark.parametrize("flags", [{"dither": True}, {"perceptual": True}, {}], ids=["dither", "perceptual", "rgb"])
+@pytest.mark.parametrize("knobs", [{}, {"SNES_H2Q_MAX": "0", "SNES_DITHER4_MAX": "0"}, {"SNES_H2Q_MAX": "100000", "SNES_DITHER4_MAX": "100000"}],
+                         ids=["default", "one-lane", "quad"])
+def test_long_lists_pin_both_kernel_families(S, img256_alpha, flags, knobs, monkeypatch):
+    """Launch groups of more than 512 candidates take the one-lane H pass (k_sparse_h2) and the one-lane resumed
+    Floyd-Steinberg (k_dither MODE 2), shorter ones the quad-per-row kernels (k_sparse_h2q, k_dither4): a 1,100-candidate list
+    (two lanes of 550 with --dither / --perceptual-palettes, one group otherwise) and a 300-candidate list, at the default
+    thresholds and with each family forced everywhere, against the dense path (SNES_SPARSE=0), bit for bit."""
+    monkeypatch.setenv("SNES_SPARSE", "0")
+    dense = S.OptimizedImage(img256_alpha, 8, 15, **flags)
+    monkeypatch.delenv("SNES_SPARSE")
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    sparse = S.OptimizedImage(img256_alpha, 8, 15, **flags)
+    dense.initialize_tiles()
+    dense.recalculate_palettes()
+    sparse.tile_palettes, sparse.palette = dense.tile_palettes, dense.palette
+    sparse.optimize()
+    pal = dense.palette
+    for (sp, si), n in (((5, 2), 1100), ((1, 14), 300)):
+        cand = S.random_candidates(31, sp * 15 + si, n)
+        cand[0] = pal[sp * 15 + si]
+        cand[1] = pal[sp * 15 + (si + 1) % 15]
+        ed = dense.score_candidates(sp, si, cand)
+        es = sparse.score_candidates(sp, si, cand)
+        assert np.array_equal(ed, es), ((sp, si), n, float(np.max(np.abs(ed - es))))
+    e_d, b_d = dense.step(S.METHOD_RANDOM, 4, 4, 0, 9, 1, 1100)  # the commit (with --dither: the winner's resumed map) from a long list
+    e_s, b_s = sparse.step(S.METHOD_RANDOM, 4, 4, 0, 9, 1, 1100)
+    assert e_d == e_s and np.array_equal(b_d, b_s) and np.array_equal(dense.palette_map, sparse.palette_map)
+    dense.close()
+    sparse.close()
+
+
 @pytest.mark.parametrize("count,size", [(8, 15), (4, 7)])
 def test_quad_dither_kernel_equals_the_one_lane_kernel(S, img256_alpha, count, size, monkeypatch):
     """k_dither4 (a quad of lanes per row: channel per lane, the entry search split four ways) against k_dither (one lane per
@@ -750,3 +783,36 @@ def test_group_step_over_rccl_equals_plain_step(S, img256):
     L.snesimage_group_destroy(grp)
     for z in (ref, twin):
         z.close()
+
+
+def test_edge_map_product_form_stays_within_bounds_on_adversarial_inputs(S, O):
+    """The product evaluates the edge-difference map as (|img2 - mu2| - a1) * r1 with r1 = 1 / (1 + a1) precomputed per image,
+    the oracle (like the crate) as (1 + |img2 - mu2|) / (1 + |img1 - mu1|) - 1: equal in exact arithmetic, ~1e-16 apart per
+    pixel in binary64.  Worst case for that difference: an image of hard edges and noise (large a1 everywhere) and candidates
+    that are near-duplicates of each other (errors a few ulps apart).  Bound the deviation, and require the ORDER of the
+    candidates' errors — what the optimizer acts on — to be the oracle's wherever the oracle's errors differ by more than it."""
+    rng = np.random.default_rng(5)
+    img = np.zeros((256, 256, 4), np.uint8)
+    img[..., :3] = rng.integers(0, 2, (256, 256, 1), dtype=np.uint8) * 255  # black / white salt and pepper
+    img[64:192, 64:192, :3] = rng.integers(0, 256, (128, 128, 3), dtype=np.uint8)  # full-range colour noise
+    img[..., 3] = 255
+    g, o = pair(S, O, img, 4, 7)
+    o.tile_palettes = (np.arange(1024) % 4).astype(np.uint8)  # (the k-means initialisers have nothing to cluster in pure noise)
+    o.palette = rng.integers(0, 32, (28, 3), dtype=np.uint8)
+    o.optimize()
+    sync_state(g, o)
+    base = np.array([16, 16, 16], np.uint8)
+    cand = np.stack([np.clip(base.astype(int) + d, 0, 31).astype(np.uint8) for d in
+                     ([0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1], [1, 1, 0], [1, 0, 1], [0, 1, 1],
+                      [-1, -1, 0], [1, -1, 0], [2, 0, 0], [0, 2, 0], [0, 0, 2], [1, 1, 1])] +
+                    [[0, 0, 0], [31, 31, 31], [31, 0, 0], [0, 31, 0]])
+    eg = g.score_candidates(1, 3, cand)
+    eo = o.score_candidates(1, 3, cand)
+    dev = np.abs(eg - eo) / np.abs(eo)
+    assert dev.max() < 1e-13, dev.max()
+    gap = 4 * np.abs(eg - eo).max()
+    for a in range(len(cand)):
+        for b in range(len(cand)):
+            if eo[a] + gap < eo[b]:
+                assert eg[a] < eg[b], (a, b)
+    g.close()
