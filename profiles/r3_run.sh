@@ -11,6 +11,6 @@ for cmd in "$@"; do
   rc=$?
   echo "== step $i rc=$rc" | tee -a "$out/steps.log"
   tail -n ${TAIL:-25} "$out/step$i.log"
-  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step $i timed out: stopping"; exit $rc; fi
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ] || [ $rc -eq 134 ] || [ $rc -eq 139 ]; then echo "step $i timed out or crashed: stopping"; exit $rc; fi
 done
 exit 0

@@ -53,8 +53,8 @@ __global__ void kb_dither_prep(const BatchArgs *__restrict__ A, const int *__res
 }
 template <int SUB> __global__ __launch_bounds__(512) void kb_dither_base(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; dither4_body<SUB, 1>(a.Db, 0); }
 __global__ __launch_bounds__(1024) void kb_dither_first(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; dither_first_body(a.Pc); }
-template <int SUB> __global__ __launch_bounds__(512) void kb_dither_run4(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; dither4_body<SUB, 2>(a.Dc, (int)blockIdx.x); }
-template <int SUB> __global__ __launch_bounds__(128) void kb_dither_run(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; dither_body<false, SUB, 2>(a.Dc, (int)blockIdx.x); }
+template <int SUB> __global__ __launch_bounds__(512) void kb_dither_run4(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; if ((int)blockIdx.x < a.n) dither4_body<SUB, 2>(a.Dc, (int)blockIdx.x); }
+template <int SUB> __global__ __launch_bounds__(128) void kb_dither_run(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; if ((int)blockIdx.x < a.n) dither_body<false, SUB, 2>(a.Dc, (int)blockIdx.x); }
 __global__ __launch_bounds__(1024) void kb_dither_diff(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; dither_diff_body(a.Pc); }
 __global__ __launch_bounds__(1024) void kb_sparse_scan(const BatchArgs *__restrict__ A, int base, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_scan_body(base ? a.Pb : a.Pc); }
 __global__ __launch_bounds__(256) void kb_base_down(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; base_down_body(a.Pb); }
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void kb_commit(const BatchArgs *__restrict__ A
 // palette and tables shared).  Call j+1 of the sequential loop sees exactly this state iff call j accepted nothing, so
 // the calls are committed in order and the window ends at the first one that changes the state: bit-identical to the
 // one-call-at-a-time loop, whatever K.
-struct WindowSlot { int method, n, slot, channel, nes, pad; unsigned long long key; };
+struct WindowSlot { int method, n, slot, channel, nes, member; unsigned long long key; int cand0, pad; }; // member / cand0: where this rank scored the call (argument block, first candidate in its storage); member < 0: another rank's
 struct WindowResult { int consumed, accepted; };
 constexpr int kMaxWindow = 1024; // calls per window over all ranks
 
@@ -164,17 +164,17 @@ __global__ __launch_bounds__(1024) void kw_commit(const WindowSlot *__restrict__
 }
 
 // --dither: the committed state's palette_map (lib.rs:237 re-runs optimize() on the winner's palette).  The winner's own
-// resumed run IS that map: adopted if its call was scored on this rank (calls [j_first, j_first + own), slot context j - j_first);
+// resumed run IS that map: adopted if its call was scored on this rank (S[j].member: its argument block, S[j].cand0: its first candidate there);
 // *skip = 1 then, and also when nothing was accepted (the stored map stands); 0 = the caller has to dither again.
-__global__ __launch_bounds__(1024) void kw_take_map(const BatchArgs *__restrict__ A, int j_first, int own, const WindowResult *__restrict__ res, const StepResult *__restrict__ log,
+__global__ __launch_bounds__(1024) void kw_take_map(const BatchArgs *__restrict__ A, const WindowSlot *__restrict__ S, const WindowResult *__restrict__ res, const StepResult *__restrict__ log,
                                                    uint8_t *__restrict__ map, int npx, int *__restrict__ skip) {
     const int consumed = res->consumed, accepted = res->accepted;
     int have = 1;
     if (accepted) {
         const int j = consumed - 1, k = log[j].best_k;
-        have = (j >= j_first && j < j_first + own) ? 1 : 0;
+        have = S[j].member >= 0 ? 1 : 0;
         if (have) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(A[j - j_first].Pc.maps + (size_t)k * npx);
+            const uint4 *src = reinterpret_cast<const uint4 *>(A[S[j].member].Pc.maps + (size_t)(S[j].cand0 + k) * npx);
             uint4 *dst = reinterpret_cast<uint4 *>(map);
             for (int i = threadIdx.x; i < npx / 16; i += 1024) dst[i] = src[i];
         }

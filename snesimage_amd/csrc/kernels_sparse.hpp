@@ -403,6 +403,7 @@ __device__ __forceinline__ void sparse_down_body(const SparseParams &P, int only
     const Geom &G = P.G;
     const int t = threadIdx.x;
     const bool is_base = P.is_base != 0;
+    if (!is_base && bx >= P.ncand) return; // (a batched launch is sized for its longest member)
     const int k = is_base ? P.base : P.k0 + bx;
     for (int i = t; i < (P.ncol + 2) * 3; i += 256) s_lin[i] = P.pal_lin[i];
     __syncthreads();

@@ -406,3 +406,29 @@ def test_reassign_tiles_lowers_the_remap_cost(O, img256):
     assert o.reassign_tiles() > 0
     assert remap_cost(o) < before
     assert o.reassign_tiles() == 0
+
+
+def test_trajectory_fixture_is_complete_and_reproducible(O):
+    """tests/golden/trajectories.json (the call-by-call oracle trajectories the GPU tests of snesimage_run_slots replay) holds
+    every case its generator lists, and the live oracle reproduces the head of one of them bit for bit."""
+    import importlib.util
+    import json
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_trajectories", os.path.join(here, "golden", "make_trajectories.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    cases = {c["name"]: c for c in json.load(open(os.path.join(here, "golden", "trajectories.json")))["cases"]}
+    assert sorted(cases) == sorted(c[0] for c in gen.CASES)
+    for name, seed, variant, count, size, flags, first, n, cseed in gen.CASES:
+        c = cases[name]
+        assert (c["seed"], c["variant"], c["count"], c["size"], c["flags"], c["first_call"], len(c["calls"]), c["cand_seed"]) == (seed, variant, count, size, flags, first, n, cseed)
+        assert c["accepted"] == sum(k[2] for k in c["calls"]) and 0 < c["accepted"] < n  # both outcomes occur in every trajectory
+    from snesimage_amd.synth import synth_image
+    c = cases["traj_rgb_2x3"]
+    o = O.OracleImage(synth_image(c["seed"], 256, 256, c["variant"]), c["count"], c["size"])
+    o.initialize_tiles()
+    o.recalculate_palettes()
+    for j, (method, p, idx, ch, _) in enumerate(O.schedule(c["count"], c["size"], 3)):
+        err, best = o.step(method, p, idx, ch, c["cand_seed"], j, 0)
+        assert float(err).hex() == c["calls"][j][0] and best.tolist() == c["calls"][j][1]
