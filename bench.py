@@ -171,6 +171,8 @@ def bench_images(args, torch, dist, S, world, rank, local_rank, device, force_di
                          "frac": value / world * ALGO_BYTES_PER_CANDIDATE / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_candidate": ALGO_BYTES_PER_CANDIDATE},
         }
+        if os.environ.get("SNES_BENCH_SHARE_GPU") == "1" or os.environ.get("SNES_BENCH_BACKEND", "nccl") != "nccl":
+            out["rehearsal"] = "ranks share one device / collective not over RCCL: a rehearsal of the N > 1 code paths, not a measurement"
         print(json.dumps(out), flush=True)
     batch.close()
     if world > 1 or force_dist:
@@ -230,6 +232,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the N > 1 code paths on a box with ONE GPU (never a measurement: the ranks share the device and the
+    # collective goes through gloo): SNES_BENCH_SHARE_GPU=1 puts every rank on device 0, SNES_BENCH_BACKEND=gloo replaces RCCL
+    if os.environ.get("SNES_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("SNES_BENCH_BACKEND", "nccl")
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d inside a %d-rank launcher environment" % (args.gpus, world))
     if not torch.cuda.is_available():
@@ -245,7 +252,10 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
             warm = torch.zeros(1, device=device)
             dist.all_reduce(warm)
             torch.cuda.synchronize()
@@ -448,6 +458,8 @@ def main():
         if stale_pmc:
             out["stale_pmc"] = stale_pmc
         out["library"] = lib_version()
+        if os.environ.get("SNES_BENCH_SHARE_GPU") == "1" or backend != "nccl":
+            out["rehearsal"] = "ranks share one device / collective over %s: a rehearsal of the N > 1 code paths, not a measurement" % backend
         out.update(extras)
         out["remap_only"] = remap
         if world == 1 and not args.no_cpu_baseline:
