@@ -112,6 +112,7 @@ struct snesimage_ctx {
     // instructions and half the runs per CU — B's own run always, the candidates' while they are few (SNES_DITHER4=0: never;
     // SNES_DITHER4_MAX: most runs per launch that still take it)
     bool dither4 = true; uint32_t dither4_max = 512;
+    bool dither_rec = true; // resumed runs take B's search result where their dithered target equals B's (SNES_DITHER_REC=0: always search)
     Geom G{};
     BlurK K{};
     size_t npx = 0, src_floats = 0;
@@ -582,7 +583,7 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
         Dp.orig = c->d_orig; Dp.tile_pal = c->d_tile_pal; Dp.pal_rgb8 = c->d_pal_rgb8; Dp.cand_tab = sp.cand_tab + 8 * (size_t)P.k0;
         Dp.maps = const_cast<uint8_t *>(P.maps); Dp.mapsC4 = const_cast<uint8_t *>(P.mapsC4);
         Dp.W = (int)c->W; Dp.H = (int)c->H; Dp.sub_size = (int)c->sub_size; Dp.ncol = c->ncol; Dp.slot_ci = sp.slot_ci;
-        Dp.first_group = sp.first; Dp.first_k0 = P.k0; Dp.ck_in = sp.ckd; Dp.bmap = sp.bmap; Dp.bmapC4 = sp.bmapC4;
+        Dp.first_group = sp.first; Dp.first_k0 = P.k0; Dp.ck_in = sp.ckd; Dp.bmap = sp.bmap; Dp.bmapC4 = sp.bmapC4; Dp.rec_in = c->dither_rec ? sp.dpack : nullptr;
         if (c->sp.lpt) { // the resumed runs differ several-fold in length: longest first (the order is rebuilt for the V pass below)
             hipLaunchKernelGGL(k_sparse_order, dim3(1), dim3(1024), 0, stream, P, sp.order + P.k0); Dp.order = sp.order + P.k0;
         }
@@ -844,6 +845,7 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     if (const char *e = getenv("SNES_BASE_STREAM")) c->sp.side = atoi(e) != 0;
     if (const char *e = getenv("SNES_LPT")) c->sp.lpt = atoi(e) != 0;
     if (const char *e = getenv("SNES_DITHER4")) c->dither4 = atoi(e) != 0;
+    if (const char *e = getenv("SNES_DITHER_REC")) c->dither_rec = atoi(e) != 0;
     if (const char *e = getenv("SNES_DITHER4_MAX")) { int v = atoi(e); if (v >= 0) c->dither4_max = (uint32_t)v; }
     if (const char *e = getenv("SNES_H2Q_MAX")) { int v = atoi(e); if (v >= 0) c->sp.h2q_max = (uint32_t)v; }
     if (const char *e = getenv("SNES_HGRID")) { int v = atoi(e); if (v >= 1) c->sp.hgrid = (uint32_t)v; }

@@ -60,6 +60,7 @@ struct DitherParams {
     const int *first_group;       // per candidate: 4-row group holding its first won pixel in raster order (H/4 if it wins nothing); P.k0 offsets the index
     int first_k0;
     const double *ck_in; const uint8_t *bmap, *bmapC4; // B's checkpoints and map (rows above the first group are B's)
+    const unsigned long long *rec_in; // B's per-pixel record (rec_pack of its MODE 1 run): where a resumed run meets B's dithered target again, B's search result stands
     const int *order;             // block b takes candidate order[b] (k_sparse_order: longest resumes first); nullptr = as listed
 };
 
@@ -163,6 +164,14 @@ __device__ __forceinline__ void dither_body(const DitherParams &P, const int blk
     // the source pixels of the NEXT x quad are fetched while the current quad is processed (the step is a dependent chain)
     const uint4 *orig4 = reinterpret_cast<const uint4 *>(P.orig);
     uint4 o_cur = make_uint4(0, 0, 0, 0), o_nxt = (y0 + j < H) ? orig4[(size_t)(y0 + j) * (W >> 2)] : make_uint4(0, 0, 0, 0);
+    // MODE 2: B's records of the same pixels, fetched with the source pixels (two 16-byte words per x quad).  The
+    // perturbation a won pixel injects fades by 0.8 per row, so away from it the run's dithered target rounds to what B's
+    // rounded to — and for the same rounded target the nearest-entry search over the fourteen other entries has B's result:
+    // only the candidate's own colour has to be tested against the key B recorded (one key instead of fifteen, exact).
+    const bool use_rec = MODE == 2 && !PERC && P.rec_in != nullptr;
+    const uint4 *rec4 = reinterpret_cast<const uint4 *>(P.rec_in);
+    uint4 ra_cur = make_uint4(0, 0, 0, 0), rb_cur = ra_cur, ra_nxt = ra_cur, rb_nxt = ra_cur;
+    if (use_rec && y0 + j < H) { ra_nxt = rec4[(size_t)(y0 + j) * (W >> 1)]; rb_nxt = rec4[(size_t)(y0 + j) * (W >> 1) + 1]; }
     for (int t = 0; t < total_steps; t++) {
         const int local = t - 2 * j; // position in this thread's 512-pixel stream
         const int x = local & (W - 1), y = y0 + j + NT * (local >> 8);
@@ -180,6 +189,10 @@ __device__ __forceinline__ void dither_body(const DitherParams &P, const int blk
                 const int ln = local + 4;
                 const int xn = ln & (W - 1), yn = y0 + j + NT * (ln >> 8);
                 if (ln < rows_per_thread * W && yn < H) o_nxt = orig4[((size_t)yn * W + xn) >> 2];
+                if (use_rec) {
+                    ra_cur = ra_nxt; rb_cur = rb_nxt;
+                    if (ln < rows_per_thread * W && yn < H) { const size_t q2 = ((size_t)yn * W + xn) >> 1; ra_nxt = rec4[q2]; rb_nxt = rec4[q2 + 1]; }
+                }
             }
             const uint32_t o = (x & 2) ? ((x & 1) ? o_cur.w : o_cur.z) : ((x & 1) ? o_cur.y : o_cur.x);
             const bool opaque = (o >> 24) != 0;
@@ -201,7 +214,21 @@ __device__ __forceinline__ void dither_body(const DitherParams &P, const int blk
             }
             int best = 0;
             uint32_t key_min = 0; // MODE 1: key of the nearest entry
-            if (!PERC) {
+            bool searched = false;
+            if (use_rec) {
+                const uint32_t rlo = (x & 2) ? ((x & 1) ? rb_cur.z : rb_cur.x) : ((x & 1) ? ra_cur.z : ra_cur.x);
+                const uint32_t rhi = (x & 2) ? ((x & 1) ? rb_cur.w : rb_cur.y) : ((x & 1) ? ra_cur.w : ra_cur.y);
+                const bool same = (rlo & 0x00ffffffu) == (tq[0] | (tq[1] << 8) | (tq[2] << 16));
+                if (!__any(!same)) { // every row of the wave is back on B's targets at its pixel: B's choice, or the candidate's colour where it beats B's key
+                    const uint32_t t1 = tq[0] | (tq[2] << 16), tw = (8u * tq[0]) | ((0u - 8u * tq[0]) << 16);
+                    const uint32_t kc = dither_group_min<1>(s_ent + P.slot_ci, t1, tw, (int)tq[1]) >> 3;
+                    const int bb = (int)(rlo >> 24) - base; // (a transparent pixel's record holds ncol + 1: its index is not used)
+                    best = (kc < rhi) ? (int)P.slot_ci - base : (opaque ? bb : 0); // rhi = 0 outside the slot's subpalette: never beaten
+                    searched = true;
+                }
+            }
+            if (searched) {
+            } else if (!PERC) {
                 const uint32_t t1 = tq[0] | (tq[2] << 16), tw = (8u * tq[0]) | ((0u - 8u * tq[0]) << 16);
                 const int tg = (int)tq[1];
                 uint32_t bk = 0xffffffffu; int bbase = 0;
