@@ -30,11 +30,11 @@ struct BatchBlock { int img, x, y; };
 __device__ __forceinline__ BatchBlock batch_block() {
     BatchBlock b;
     const int X = (int)gridDim.x, Y = (int)gridDim.y, K = (int)gridDim.z;
-    if (K % 8 != 0) { b.img = (int)blockIdx.z; b.x = (int)blockIdx.x; b.y = (int)blockIdx.y; return b; }
+    const int per = X * Y, K8 = K & ~7; // the members beyond the last multiple of eight (a window of channel calls rarely holds a multiple) are placed plainly
     const int L = (int)blockIdx.x + X * ((int)blockIdx.y + Y * (int)blockIdx.z);
-    const int per = X * Y, idx = L >> 3;
-    b.img = (L & 7) + 8 * (idx / per);
-    const int rem = idx % per;
+    int rem;
+    if (L < per * K8) { const int idx = L >> 3; b.img = (L & 7) + 8 * (idx / per); rem = idx % per; }
+    else { const int L2 = L - per * K8; b.img = K8 + L2 / per; rem = L2 % per; }
     b.x = rem % X; b.y = rem / X;
     return b;
 }
