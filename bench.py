@@ -115,7 +115,7 @@ def bench_images(args, torch, dist, S, world, rank, local_rank, device, force_di
     sub_count, sub_size = 8, 15
     mine = shard_images(args.images * world, rank, world)
     batch = ImageBatch.synthetic(mine, sub_count, sub_size, device=local_rank, candidates=args.batch, host_threads=args.host_threads,
-                                 batched=not args.per_image_launches, groups=args.groups, perceptual=args.perceptual)
+                                 batched=not args.per_image_launches, groups=args.groups, perceptual=args.perceptual, dither=args.dither)
     t_init = time.perf_counter()
     batch.initialize(drop_failed=True)  # untimed: TileAssignment + Clustering of every image (the k-means initialisers)
     torch.cuda.synchronize()
@@ -147,7 +147,7 @@ def bench_images(args, torch, dist, S, world, rank, local_rank, device, force_di
         # passes of this mode, scaled by the candidates per step; null for variants without a committed measurement
         traffic, traffic_src = None, None
         try:
-            if not args.perceptual and not args.per_image_launches:
+            if not args.perceptual and not args.dither and not args.per_image_launches:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_images.json")))
                 per_call = sum(k["hbm_bytes_corrected_per_dispatch"] * k["FETCH_SIZE"]["dispatches"] for n, k in pmc["kernels"].items()
                                if "::kb_" in n and "hbm_bytes_corrected_per_dispatch" in k) / float(pmc["calls"])
@@ -160,9 +160,10 @@ def bench_images(args, torch, dist, S, world, rank, local_rank, device, force_di
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "throughput mode: %d synthetic 256x256 RGBA8 images per GPU (seeds 0x5EED0000+i), 8 subpalettes x 15, "
-                                   "%s, no dither, %d candidates per optimizer call per image, one call on every "
+                                   "%s, %s, %d candidates per optimizer call per image, one call on every "
                                    "image per step, remap + SSIMULACRA2 per candidate, no collective" % (
-                                       len(mine), "CIEDE2000 (--perceptual-palettes)" if args.perceptual else "RGB redmean distance", args.batch),
+                                       len(mine), "CIEDE2000 (--perceptual-palettes)" if args.perceptual else "RGB redmean distance",
+                                       "Floyd-Steinberg dither" if args.dither else "no dither", args.batch),
                        "images_per_gpu": len(batch), "dropped_at_init": batch.dropped, "init_seconds": t_init, "batch": args.batch, "config": "images", "host_threads": args.host_threads,
                        "launches": "per image" if args.per_image_launches else "one per stage for all images",
                        "mean_final_error": sum(errs) / len(errs)},
@@ -191,6 +192,7 @@ def main():
     ap.add_argument("--images", type=int, default=128, help="--config images: images per GPU (1,024 over 8 GPUs)")
     ap.add_argument("--host-threads", type=int, default=16, help="--config images: host threads initialising images / enqueueing per-image calls")
     ap.add_argument("--perceptual", action="store_true", help="--config images: CIEDE2000 distance (--perceptual-palettes)")
+    ap.add_argument("--dither", action="store_true", help="--config images: Floyd-Steinberg dither (--dither)")
     ap.add_argument("--groups", type=int, default=4, help="--config images: batches stepped side by side on their own streams")
     ap.add_argument("--per-image-launches", action="store_true",
                     help="--config images: one stream and one set of launches per image instead of one launch per stage for all images")

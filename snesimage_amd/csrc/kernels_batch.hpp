@@ -16,7 +16,7 @@ struct BatchArgs {
     const float *lab_eotf; float *cand_lab; // --perceptual-palettes
     // --dither (slot windows): Floyd-Steinberg of the call's base image B (k_dither4 MODE 1: the slot's entry stands in for
     // entry j0 of its subpalette, colour bcolor -> table row btab) and the candidates' resumed runs (MODE 2)
-    DitherParams Db, Dc; const unsigned long long *win_pack; const uint8_t *bcolor; float *btab; int *zero; int nzero;
+    DitherParams Db, Dc; const unsigned long long *win_pack; const uint8_t *bcolor; float *btab; int *zero; int nzero; uint8_t *map;
 };
 
 // `dead` (optional device flag): nonzero = this launch belongs to a slot window that an earlier window has voided: leave at once
@@ -77,6 +77,16 @@ __global__ __launch_bounds__(1024) void kb_sparse_order(const BatchArgs *__restr
 __global__ __launch_bounds__(256, 2) void kb_sparse_v(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_v_body<false, 2, 2>(a.Pc, (int)blockIdx.y + a.Pc.s_first); }
 __global__ void kb_final_score(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; final_score_body(a.part, a.n, a.Pc.G, a.errors, 1, 0, a.Pc.item_count, (int)kItemLists); }
 __global__ __launch_bounds__(256) void kb_commit(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; commit_body(a.errors, a.n, a.cand, a.colors, a.slot, a.nes, a.inc_err, a.last, a.T); }
+// --dither, image batches: lib.rs:237's optimize() of the committed palette is the winner's own resumed run (every candidate of
+// an image is scored on this device, so it is always at hand); nothing accepted: the stored map stands
+__global__ __launch_bounds__(1024) void kb_take_map(const BatchArgs *__restrict__ A, const int *__restrict__ dead) {
+    SNES_BATCH_IMG;
+    const int k = a.last->best_k;
+    if (k < 0) return;
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.Pc.maps + (size_t)k * a.npx);
+    uint4 *dst = reinterpret_cast<uint4 *>(a.map);
+    for (int i = threadIdx.x; i < a.npx / 16; i += 1024) dst[i] = src[i];
+}
 #undef SNES_BATCH_IMG
 #undef SNES_BATCH_XCD
 

@@ -17,7 +17,7 @@ def test_shard_images_is_a_partition(n, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("batched,flags", [(False, {}), (True, {}), (True, {"perceptual": True})])
+@pytest.mark.parametrize("batched,flags", [(False, {}), (True, {}), (True, {"perceptual": True}), (True, {"dither": True})])
 def test_concurrent_images_equal_one_at_a_time(batched, flags):
     """Optimizer calls of several images — enqueued side by side from several host threads, or issued as one launch per
     stage for all of them — give, for every image, exactly the state that stepping that image alone gives."""
@@ -49,7 +49,7 @@ def test_concurrent_images_equal_one_at_a_time(batched, flags):
 def test_batch_rejects_what_it_does_not_cover():
     import snesimage_amd as S
     from snesimage_amd.throughput import ImageBatch
-    for flags in ({"dither": True}, {"dither": True, "perceptual": True}):
+    for flags in ({"dither": True, "perceptual": True},):  # (CIEDE2000 inside Floyd-Steinberg stays on the dense path)
         b = ImageBatch.synthetic([1, 2], 2, 3, candidates=8, batched=True, **flags)
         with pytest.raises(S.SnesImageError) as e:
             b.initialize()
@@ -151,13 +151,13 @@ def _throughput_golden(name):
         return next(c for c in json.load(f)["throughput"] if c["name"] == name)
 
 
-def _run_batched(S, perceptual, calls, images, groups):
+def _run_batched(S, perceptual, calls, images, groups, dither=False):
     """The call list through snesimage_batch_step_async (one launch per stage for all images of a group)."""
     from snesimage_amd import _ffi
     from snesimage_amd.synth import synth_image
     from snesimage_amd.throughput import ImageBatch
     batch = ImageBatch(((gid, synth_image(seed, 256, 256, variant)) for gid, seed, variant in images), 8, 15, candidates=64,
-                       batched=True, groups=groups, perceptual=perceptual)
+                       batched=True, groups=groups, perceptual=perceptual, dither=dither)
     batch.initialize()
     assert batch.dropped == []
     L = _ffi.load()
@@ -223,4 +223,38 @@ def test_batched_throughput_mode_matches_oracle_at_8x15(O, perceptual):
             img = batch.images[pos]
             assert np.array_equal(img.palette, solo.palette) and np.array_equal(img.palette_map, solo.palette_map) and es == errs[pos]
             solo.close()
+    batch.close()
+
+
+@pytest.mark.gpu
+def test_batched_throughput_mode_with_dither_matches_oracle(O):
+    """Throughput mode with --dither (round 3: the batched Floyd-Steinberg kernels): three 256x256 images incl. the
+    transparent-square variant, 8 x 15, the reference's 64 / 32 candidates per call — random calls, a slot revisited after
+    its commit, a channel sweep — against the ORACLE stepping every image alone: palette, palette_map (the winner's resumed
+    run adopted as the committed map), per-call error, JSON."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import snesimage_amd as S
+    import golden.make_golden as M
+    from snesimage_amd.synth import synth_image
+
+    calls = [(0, 0, 0, 0), (0, 3, 7, 0), (1, 3, 7, 1), (0, 3, 7, 0)]
+    images = M.THROUGHPUT_IMAGES[:3]
+    assert any(v == 1 for _, _, v in images)
+    batch, errs = _run_batched(S, False, calls, images, groups=1, dither=True)
+
+    def alone(a):
+        gid, seed, variant = a
+        o = O.OracleImage(synth_image(seed, 256, 256, variant), 8, 15, dither=True)
+        o.initialize_tiles()
+        o.recalculate_palettes()
+        return o, [o.step(m, p, i, ch, 1 + gid, j, 64 if m == 0 else 0)[0] for j, (m, p, i, ch) in enumerate(calls)]
+
+    with ThreadPoolExecutor(len(images)) as ex:
+        oracle = list(ex.map(alone, images))
+    for pos, (o, oerrs) in enumerate(oracle):
+        img = batch.images[pos]
+        assert np.array_equal(img.palette, o.palette) and np.array_equal(img.palette_map, o.palette_map), pos
+        assert img.as_json() == o.as_json()
+        assert np.max(np.abs(np.array(errs[pos]) - np.array(oerrs)) / np.array(oerrs)) < 1e-11
     batch.close()
