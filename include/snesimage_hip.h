@@ -123,7 +123,7 @@ int32_t snesimage_run_slots(snesimage_ctx *ctx, uint32_t n_calls, uint64_t seed,
 /* Allocate the storage of windows of up to n_slots calls now instead of on first use (about 0.3 GB of HBM per call; the
  * library never takes more than SNES_WINDOW_MAX, default 64, calls per window). */
 int32_t snesimage_slots_reserve(snesimage_ctx *ctx, uint32_t n_slots);
-/* The two phases of one window, for sharding its calls over GPUs (the window's calls in blocks of ceil(n / shard_count) consecutive calls, rank r the r-th block: its own base
+/* The two phases of one window, for sharding its calls over GPUs (the window's calls in runs of six consecutive calls, round robin over the ranks: every call its own base
  * image, its own candidates).  Phase 1 takes at most n_slots calls from the given scheduler state — fewer where the method
  * changes, all calls of a window having the same number of candidates (*stride) — and writes errors[j * stride + k]
  * (device, n_slots * 64 doubles; +inf for calls of other ranks; NULL = the context's own vector, single rank only);
@@ -151,7 +151,7 @@ int32_t snesimage_group_step(snesimage_group *group, uint32_t method, uint32_t p
                              uint32_t channel, uint64_t seed, uint64_t step_id, uint32_t n_total,
                              double *best_error, uint8_t *best_rgb5 /*3*/);
 
-/* snesimage_run_slots over a group: the calls of every window are dealt to the members (member r the r-th block of consecutive calls), one grouped
+/* snesimage_run_slots over a group: the calls of every window are dealt to the members (runs of six consecutive calls, round robin), one grouped
  * RCCL all-reduce(min) over the window's error vector, identical in-order commit on every member.  Same arguments, same
  * trajectory (lib.rs:888-933), bit-identical palettes on all devices.  Every member must be in the state
  * snesimage_group_create asks for. */

@@ -9,7 +9,7 @@ replicated work on B and the pack, its share of the candidates, the commit) and 
 of n doubles (latency-bound, ~10-20 us over xGMI).  Prints one JSON object.
 
 --windows K1,K2,...: the same for the slot windows of the reference's loop (snesimage_slots_begin / _commit): a window of K
-calls x 64 candidates, its calls dealt to G ranks in blocks of consecutive calls (own base images, own candidates).  Rank 0's share is
+calls x 64 candidates, its calls dealt to G ranks in runs of six consecutive calls (own base images, own candidates).  Rank 0's share is
 timed; a rank takes at most 64 calls of a window, so a single GPU works through K calls as K/64 windows in a row.
 """
 import argparse

@@ -66,8 +66,8 @@ def sharded_step(scorer, method, palette, index, channel, seed, step_id, n_total
 # ---- slot windows: the reference's own loop (64 / 32 / 56 candidates per call), calls dealt to the ranks -----------------
 #
 # `sharded_step` splits ONE call's candidates; its base image is computed by every rank.  A *window* (DESIGN.md,
-# snesimage_run_slots) holds K consecutive calls of the schedule, all scored against the same palette: rank r takes the r-th block of
-# ceil(K / world) consecutive calls — their own base images, their own candidates — and the only exchange is ONE min-all-reduce over the
+# snesimage_run_slots) holds K consecutive calls of the schedule, all scored against the same palette: the calls are dealt to the
+# ranks in runs of six consecutive calls, round robin — every call its own base image, its own candidates — and the only exchange is ONE min-all-reduce over the
 # window's K x n error vector.  Every rank then applies the calls' decisions in order and stops behind the first call that
 # changed the palette (lib.rs:216-219: strict <), so the ranks stay bit-identical without a broadcast and the trajectory is
 # the reference's, call for call.

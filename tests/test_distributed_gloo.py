@@ -119,7 +119,7 @@ def test_two_rank_sharded_steps_match_single_process(O):
 # ---- slot windows: the calls of a window dealt to the ranks (snesimage_amd.distributed.sharded_run_slots) -------------------
 class OracleWindowScorer:
     """slots_begin / slots_commit protocol of HipWindowScorer over the CPU oracle: K consecutive calls of the schedule scored
-    against the current palette (rank r the r-th block of consecutive calls), then committed in order up to the first call that accepts."""
+    against the current palette (runs of six consecutive calls dealt round robin), then committed in order up to the first call that accepts."""
 
     def __init__(self, image, O, count, size):
         self.o, self.O, self.count, self.size = image, O, count, size
@@ -135,7 +135,6 @@ class OracleWindowScorer:
             st = schedule_advance(self.count, self.size, st, 1)
         n = 64 if calls[0][0] == 0 else 32
         errs = torch.full((len(calls) * n,), float("inf"), dtype=torch.float64)
-        block = (len(calls) + world - 1) // world
         self.cands = []
         for j, (method, p, i, ch) in enumerate(calls):
             if method == 0:
@@ -144,7 +143,7 @@ class OracleWindowScorer:
                 cand = np.repeat(o.palette[p * o.sub_size + i][None, :], 32, 0)
                 cand[:, ch] = np.arange(32)
             self.cands.append(cand)
-            if j // block == rank:
+            if (j // 6) % world == rank:  # runs of six consecutive calls, round robin
                 errs[j * n:(j + 1) * n] = torch.from_numpy(o.score_candidates(p, i, cand))
         self.calls, self.n, self.incumbent = calls, n, o.error()
         return errs, len(calls), n
