@@ -70,6 +70,9 @@ __global__ __launch_bounds__(256) void kb_sparse_scan_lab(const BatchArgs *__res
 __global__ __launch_bounds__(64) void kb_sparse_h(const BatchArgs *__restrict__ A, int base, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_h_body(base ? a.Pb : a.Pc); }
 __global__ __launch_bounds__(64) void kb_sparse_h2(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_h2_dispatch<false>(a.Pc, bb.y, bb.x, (int)gridDim.x); }
 __global__ __launch_bounds__(64) void kb_sparse_h2_base(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_h2_dispatch<true>(a.Pb, bb.y, bb.x, (int)gridDim.x); }
+// the quad-per-row H pass (a third of the chain per column quad for four times the waves): short windows, whose stages are latency
+__global__ __launch_bounds__(64) void kb_sparse_h2q(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_h2q_dispatch<false>(a.Pc, bb.y, bb.x, (int)gridDim.x); }
+__global__ __launch_bounds__(64) void kb_sparse_h2q_base(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_h2q_dispatch<true>(a.Pb, bb.y, bb.x, (int)gridDim.x); }
 __global__ __launch_bounds__(256, 5) void kb_sparse_v2(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; if (bb.y < a.Pc.G.nscales && a.Pc.G.sw[bb.y] >= 64) sparse_v2_body<false>(a.Pc, bb.y, bb.x); }
 __global__ __launch_bounds__(256) void kb_sparse_v_base(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; if (bb.y < a.Pb.G.nscales && a.Pb.G.sw[bb.y] >= 64) sparse_v2_body<true>(a.Pb, bb.y, bb.x); }
 __global__ __launch_bounds__(256, 1) void kb_sparse_v_base_narrow(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_v_base_narrow_dispatch(a.Pb); }
