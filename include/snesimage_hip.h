@@ -105,7 +105,7 @@ int32_t snesimage_step_commit(snesimage_ctx *ctx, const double *d_errors);
  * (strict <, lib.rs:216-219), so a *window* scores the next K calls of the schedule against the current palette in one set
  * of launches, applies their decisions in order and stops behind the first call that changed the state; the calls behind
  * it are void and are scored again by the next window.  Bit-identical to snesimage_schedule_next + snesimage_step per
- * call, for every K.  Windows cover the group-sparse path (256 rows; not --dither together with --perceptual-palettes); other configurations are stepped call
+ * call, for every K.  Windows cover the group-sparse path (32 rows and more; not --dither together with --perceptual-palettes); other configurations are stepped call
  * by call inside snesimage_run_slots. */
 typedef struct { double error; int32_t best_k; uint8_t rgb5[3]; uint8_t changed; } snesimage_call_result; /* what snesimage_last_step reports after the call */
 typedef struct {

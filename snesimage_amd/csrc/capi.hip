@@ -839,8 +839,8 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     c->K = make_blur_constants();
     if (const char *e = getenv("SNES_CHUNK")) { int v = atoi(e); if (v > 0) c->chunk = (uint32_t)v; }
     if (const char *e = getenv("SNES_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->nlanes = (uint32_t)v; }
-    // the group-sparse path covers, at the full size, the no-dither remap (RGB keys or CIEDE2000) and the RGB Floyd-Steinberg remap
-    c->sp.enabled = (h == 256) && !(c->dither && c->perceptual);
+    // the group-sparse path covers the no-dither remap (RGB keys or CIEDE2000) and the RGB Floyd-Steinberg remap
+    c->sp.enabled = (h >= 32) && !(c->dither && c->perceptual); // (B's downscale walks 32 x 32 blocks of pixels)
     if (const char *e = getenv("SNES_SPARSE")) c->sp.enabled = c->sp.enabled && atoi(e) != 0;
     if (const char *e = getenv("SNES_BASE_STREAM")) c->sp.side = atoi(e) != 0;
     if (const char *e = getenv("SNES_LPT")) c->sp.lpt = atoi(e) != 0;

@@ -276,7 +276,7 @@ __device__ __forceinline__ void sparse_scan_body(const SparseParams &P) {
     const bool live = P.is_base ? (wi == 0) : (wi < P.ncand);
     const int k = P.is_base ? P.base : P.k0 + (live ? wi : 0);
     unsigned long long mask = 0ull; int xmin = G.W, won = 0;
-    if (P.is_base) { mask = ~0ull; xmin = 0; }
+    if (P.is_base) { const int ng0 = G.sh[0] >> 2; mask = ng0 >= 64 ? ~0ull : ((1ull << ng0) - 1ull); xmin = 0; } // every group of the image (64 at 256 rows)
     else {
         const uint32_t crgb = __float_as_uint(P.cand_tab[8 * (size_t)k + 6]);
         const int n = *P.plist_count;

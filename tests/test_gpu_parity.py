@@ -816,3 +816,44 @@ def test_edge_map_product_form_stays_within_bounds_on_adversarial_inputs(S, O):
             if eo[a] + gap < eo[b]:
                 assert eg[a] < eg[b], (a, b)
     g.close()
+
+
+@pytest.mark.parametrize("h", [32, 64, 128])
+@pytest.mark.parametrize("flags", [{}, {"dither": True}, {"perceptual": True}], ids=["rgb", "dither", "perceptual"])
+def test_small_heights_sparse_path_equals_dense_path(S, O, h, flags, monkeypatch):
+    """Heights below 256 (down to 32 rows: B's downscale walks 32 x 32 blocks) on the group-sparse path: the narrowest
+    scales are a single 4-row group there.  Against the dense path bit for bit, a handful against the oracle, and the slot
+    windows against call-by-call stepping."""
+    from snesimage_amd.synth import synth_image
+    img = synth_image(0x5EED0020 + h, 256, h, 1 if h == 64 else 0)
+    monkeypatch.setenv("SNES_SPARSE", "0")
+    dense = S.OptimizedImage(img, 4, 7, **flags)
+    monkeypatch.setenv("SNES_SPARSE", "1")
+    monkeypatch.setenv("SNES_SPARSE_MIN", "1")
+    sparse = S.OptimizedImage(img, 4, 7, **flags)
+    dense.initialize_tiles()
+    dense.recalculate_palettes()
+    sparse.tile_palettes, sparse.palette = dense.tile_palettes, dense.palette
+    sparse.optimize()
+    pal = dense.palette
+    for (sp, si), n in (((1, 2), 150), ((3, 6), 40)):
+        cand = S.random_candidates(13, sp * 7 + si + h, n)
+        cand[0] = pal[sp * 7 + si]
+        cand[1] = pal[sp * 7 + (si + 1) % 7]
+        ed, es = dense.score_candidates(sp, si, cand), sparse.score_candidates(sp, si, cand)
+        assert np.array_equal(ed, es), (h, sp, si, float(np.max(np.abs(ed - es))))
+    o = O.OracleImage(img, 4, 7, **flags)
+    o.tile_palettes, o.palette = dense.tile_palettes, dense.palette
+    o.optimize()
+    assert rel(es[:5], o.score_candidates(3, 6, cand[:5])) < REL_ERR
+    sched = S.schedule(4, 7, 60)
+    state = sched[20][1:]
+    log, _, stats = sparse.run_slots(40, seed=3, first_step_id=20, state=state)
+    for j in range(40):
+        m, p, i, ch, _ = sched[20 + j]
+        e, b = dense.step(m, p, i, ch, 3, 20 + j, 0)
+        assert (e, b.tolist()) == (log[j][0], log[j][2].tolist()), (h, j)
+    assert np.array_equal(dense.palette, sparse.palette) and np.array_equal(dense.palette_map, sparse.palette_map)
+    assert stats["windows"] < 40
+    dense.close()
+    sparse.close()
