@@ -413,7 +413,7 @@ __device__ __forceinline__ void sparse_down_body(const SparseParams &P, int only
     const CandMeta *M = P.meta + k;
     float *mine = P.store + (size_t)k * P.S.cand_stride;
     const float *basep = P.store + (size_t)P.base * P.S.cand_stride;
-    const int s_lo = only_scale > 0 ? only_scale : 1, s_hi = only_scale > 0 ? only_scale + 1 : G.nscales;
+    const int s_lo = only_scale > 0 ? only_scale : (only_scale < 0 ? -only_scale : 1), s_hi = only_scale > 0 ? only_scale + 1 : G.nscales; // only_scale < 0: from scale -only_scale on
     const int part0 = is_base ? bx : 0, nparts = is_base ? (int)gridDim.x : 1;
     for (int s = s_lo; s < s_hi; s++) {
         const int Ws = G.sw[s], Wp = G.sw[s - 1];
@@ -468,6 +468,64 @@ __device__ __forceinline__ void sparse_down_body(const SparseParams &P, int only
             }
         }
         __syncthreads(); // the rows written above are read by this block at the next scale
+    }
+}
+
+// ---- scale 1 of the candidates' downscale, one block per changed group ---------------------------------------------------
+// Scale 1 holds three quarters of the pixels sparse_down_body computes and reads nothing that body writes (its inputs are
+// the pack and the win test), so it need not wait its turn in a block that walks a candidate's scales one after the
+// other: the scan's item lists of scale 1 name every (candidate, changed group) — three items per group, one per channel —
+// and a block of 256 threads takes one group (4 rows x W/2 pixels).  Same arithmetic, same stores as the s == 1 branch there.
+__device__ __forceinline__ void sparse_down1_body(const SparseParams &P, const int bx, const int gx) {
+    __shared__ float s_lin[256 * 3];
+    const Geom &G = P.G;
+    const int t = threadIdx.x;
+    const int Ws = G.sw[1];
+    for (int i = t; i < (P.ncol + 2) * 3; i += 256) s_lin[i] = P.pal_lin[i];
+    const int nb = Ws >= 64 ? (Ws >> 6) : 1; // item lists of scale 1: one per first column block
+    int total = 0, cnt[kColBuckets];
+#pragma unroll
+    for (int b = 0; b < kColBuckets; b++) { cnt[b] = b < nb ? P.item_count[kColBuckets + b] / 3 : 0; total += cnt[b]; }
+    __syncthreads();
+    for (int gi = bx; gi < total; gi += gx) {
+        int b = 0, li = gi;
+        while (li >= cnt[b]) { li -= cnt[b]; b++; }
+        const unsigned int it = P.items[(size_t)(kColBuckets + b) * P.item_stride + 3 * (size_t)li]; // channel 0's item of the group
+        const int k = (int)(it >> 8), j = (int)((it >> 2) & 63u);
+        const CandMeta *M = P.meta + k;
+        const int g = M->glist[P.S.goff[1] + j];
+        float *mine = P.store + (size_t)k * P.S.cand_stride;
+        const uint32_t crgb = __float_as_uint(P.cand_tab[8 * (size_t)k + 6]);
+        const float cl0 = P.cand_tab[8 * (size_t)k], cl1 = P.cand_tab[8 * (size_t)k + 1], cl2 = P.cand_tab[8 * (size_t)k + 2];
+        float *ol = mine + P.S.off_lin[1] + (size_t)j * 12 * Ws;
+        float *oc = mine + P.S.off_xybC[1] + (size_t)j * 12 * Ws, *orr = mine + P.S.off_xybR[1] + (size_t)j * 12 * Ws;
+        for (int rem = t; rem < 4 * Ws; rem += 256) {
+            const int r = (rem >> 2) & 3, x = ((rem >> 4) << 2) | (rem & 3);
+            const int y = 4 * g + r;
+            float sum[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int iy = 0; iy < 2; iy++)
+#pragma unroll
+                for (int ix = 0; ix < 2; ix++) {
+                    const int px0 = (2 * y + iy) * G.W + 2 * x + ix;
+                    const unsigned long long w = P.pack[px0];
+                    const uint32_t ci = P.use_maps ? maps_ci(P, P.maps + (size_t)(k - P.k0) * G.W * G.H, false, 2 * x + ix, 2 * y + iy, (uint32_t)w)
+                                      : (P.perceptual ? (won_bit(P.bitmap + (size_t)k * (G.W * G.H / 32), px0) ? (uint32_t)P.ncol : ((uint32_t)w >> 24))
+                                                      : sparse_ci((uint32_t)w, (uint32_t)(w >> 32), crgb, (uint32_t)P.ncol));
+                    const bool cw = ci == (uint32_t)P.ncol; // the candidate's own colour stands at table row ncol
+                    sum[0] += cw ? cl0 : s_lin[3 * ci]; sum[1] += cw ? cl1 : s_lin[3 * ci + 1]; sum[2] += cw ? cl2 : s_lin[3 * ci + 2];
+                }
+            const float v[3] = {sum[0] * 0.25f, sum[1] * 0.25f, sum[2] * 0.25f};
+            float X, Y, B;
+            linear_to_positive_xyb(v[0], v[1], v[2], X, Y, B);
+            const float xyb[3] = {X, Y, B};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                ol[(size_t)c * 4 * Ws + (size_t)(x >> 2) * 16 + r * 4 + (x & 3)] = v[c];
+                oc[(size_t)c * 4 * Ws + (size_t)(x >> 2) * 16 + r * 4 + (x & 3)] = xyb[c];
+                if (Ws < 64) orr[(size_t)c * 4 * Ws + (size_t)x * 4 + r] = xyb[c];
+            }
+        }
     }
 }
 
@@ -1002,6 +1060,7 @@ __global__ __launch_bounds__(1024) void k_sparse_scan(SparseParams P) { sparse_s
 __global__ __launch_bounds__(1024) void k_dither_first(SparseParams P) { dither_first_body(P); }
 __global__ __launch_bounds__(1024) void k_dither_diff(SparseParams P) { dither_diff_body(P); }
 __global__ __launch_bounds__(256) void k_sparse_down(SparseParams P, int only_scale) { sparse_down_body(P, only_scale, (int)blockIdx.x); }
+__global__ __launch_bounds__(256) void k_sparse_down1(SparseParams P) { sparse_down1_body(P, (int)blockIdx.x, (int)gridDim.x); }
 __global__ __launch_bounds__(256) void k_base_down(SparseParams P) { base_down_body(P); }
 __global__ __launch_bounds__(64) void k_sparse_h(SparseParams P) { sparse_h_body(P); }
 __global__ __launch_bounds__(256, 1) void k_sparse_v_base(SparseParams P) { sparse_v_base_body(P); }
