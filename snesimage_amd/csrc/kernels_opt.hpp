@@ -151,7 +151,7 @@ __device__ __forceinline__ void dither_body(const DitherParams &P, const int blk
     const double *ckp = MODE == 2 ? P.ck_in + (size_t)(y0 >> 2) * W * 3 : nullptr;
     double ck_n[3] = {0.0, 0.0, 0.0}; // column t + 2 of the checkpoint, fetched a step ahead
     if (ck_feed) {
-        for (int c = 0; c < 3; c++) { ring[j][0][c] = ckp[c]; ring[j][1][c] = ckp[3 + c]; ck_n[c] = ckp[6 + c]; }
+        for (int c = 0; c < 3; c++) { ring[j][0][c] = ckp[c] * mult; ring[j][1][c] = ckp[3 + c] * mult; ck_n[c] = ckp[6 + c] * mult; }
     }
     __syncthreads();
     const int nrows = H - y0;
@@ -202,10 +202,12 @@ __device__ __forceinline__ void dither_body(const DitherParams &P, const int blk
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 double acc = 0.0;
-                const double a0 = acc + r0[c] * mult * w3; acc = hasUL ? a0 : acc;
-                const double a1 = acc + r1[c] * mult * w2; acc = hasU ? a1 : acc;
-                const double a2 = acc + r2[c] * mult * w1; acc = hasUR ? a2 : acc;
-                const double a3 = acc + left[c] * mult * w0; acc = hasL ? a3 : acc;
+                // (the ring and `left` hold value * 0.8 — lib.rs:477-496 multiplies every diffused value by the error multiplier
+                // first, then by the neighbour's weight: the first product is the same for the four neighbours it goes to)
+                const double a0 = acc + r0[c] * w3; acc = hasUL ? a0 : acc;
+                const double a1 = acc + r1[c] * w2; acc = hasU ? a1 : acc;
+                const double a2 = acc + r2[c] * w1; acc = hasUR ? a2 : acc;
+                const double a3 = acc + left[c] * w0; acc = hasL ? a3 : acc;
                 e[c] = acc;
                 target[c] = (double)((o >> (8 * c)) & 0xff) + acc;
                 const double cl = fmin(fmax(target[c], 0.0), 255.0);
@@ -284,17 +286,17 @@ __device__ __forceinline__ void dither_body(const DitherParams &P, const int blk
             for (int c = 0; c < 3; c++) {
                 const double d = target[c] - (double)((nc >> (8 * c)) & 0xff);
                 v[c] = opaque ? d : e[c]; // transparent pixels forward their incoming error (lib.rs:469-474)
-                left[c] = v[c];
+                left[c] = v[c] * mult;
             }
             // Row y-1 is two columns ahead (t = x + 2y): at this step it writes slot (x+2)&3 while this thread read slots
             // (x-1), x, (x+1) & 3 — never the same slot, so one barrier per step orders everything.
-            ring[j][x & 3][0] = v[0]; ring[j][x & 3][1] = v[1]; ring[j][x & 3][2] = v[2];
+            ring[j][x & 3][0] = left[0]; ring[j][x & 3][1] = left[1]; ring[j][x & 3][2] = left[2];
             if (MODE == 1 && (y & 3) == 3 && y + 1 < H) { double *co = P.ck_out + ((size_t)((y + 1) >> 2) * W + x) * 3; co[0] = v[0]; co[1] = v[1]; co[2] = v[2]; }
         }
         if (MODE == 2 && ck_feed && t + 2 < W) { // row y0 - 1, column t + 2 (this thread's own stream starts at step 2 (NT - 1) = W - 2)
             const int xc = t + 2;
             ring[j][xc & 3][0] = ck_n[0]; ring[j][xc & 3][1] = ck_n[1]; ring[j][xc & 3][2] = ck_n[2];
-            if (xc + 1 < W) { ck_n[0] = ckp[3 * (xc + 1)]; ck_n[1] = ckp[3 * (xc + 1) + 1]; ck_n[2] = ckp[3 * (xc + 1) + 2]; }
+            if (xc + 1 < W) { ck_n[0] = ckp[3 * (xc + 1)] * mult; ck_n[1] = ckp[3 * (xc + 1) + 1] * mult; ck_n[2] = ckp[3 * (xc + 1) + 2] * mult; }
         }
         __syncthreads();
     }
@@ -353,7 +355,7 @@ __device__ __forceinline__ void dither4_body(const DitherParams &P, const int bl
     const bool ck_feed = MODE == 2 && j == NT - 1 && y0 > 0 && q < 3;
     const double *ckp = MODE == 2 ? P.ck_in + (size_t)(y0 >> 2) * W * 3 : nullptr;
     double ck_n = 0.0;
-    if (ck_feed) { ring[j][0][q] = ckp[q]; ring[j][1][q] = ckp[3 + q]; ck_n = ckp[6 + q]; }
+    if (ck_feed) { ring[j][0][q] = ckp[q] * mult; ring[j][1][q] = ckp[3 + q] * mult; ck_n = ckp[6 + q] * mult; }
     __syncthreads();
     const int nrows = H - y0;
     const int rows_per_thread = (nrows + NT - 1) / NT;
@@ -381,10 +383,10 @@ __device__ __forceinline__ void dither4_body(const DitherParams &P, const int bl
             const bool opaque = (o >> 24) != 0;
             const bool hasU = y > 0, hasL = x > 0, hasUL = hasU && hasL, hasUR = hasU && (x + 1 < W);
             double acc = 0.0;
-            const double a0 = acc + r0 * mult * w3; acc = hasUL ? a0 : acc;
-            const double a1 = acc + r1 * mult * w2; acc = hasU ? a1 : acc;
-            const double a2 = acc + r2 * mult * w1; acc = hasUR ? a2 : acc;
-            const double a3 = acc + left * mult * w0; acc = hasL ? a3 : acc;
+            const double a0 = acc + r0 * w3; acc = hasUL ? a0 : acc; // (ring and `left` hold value * 0.8: see dither_body)
+            const double a1 = acc + r1 * w2; acc = hasU ? a1 : acc;
+            const double a2 = acc + r2 * w1; acc = hasUR ? a2 : acc;
+            const double a3 = acc + left * w0; acc = hasL ? a3 : acc;
             const double e = acc;
             const double target = (double)((o >> (8 * c)) & 0xff) + acc;
             const double cl = fmin(fmax(target, 0.0), 255.0);
@@ -436,16 +438,16 @@ __device__ __forceinline__ void dither4_body(const DitherParams &P, const int bl
             const uint32_t nc = s_ent[base + best].w;
             const double dres = target - (double)((nc >> (8 * c)) & 0xff);
             const double v = opaque ? dres : e; // transparent pixels forward their incoming error (lib.rs:469-474)
-            left = v;
+            left = v * mult;
             if (q < 3) {
-                ring[j][x & 3][q] = v;
+                ring[j][x & 3][q] = left;
                 if (MODE == 1 && (y & 3) == 3 && y + 1 < H) P.ck_out[((size_t)((y + 1) >> 2) * W + x) * 3 + q] = v;
             }
         }
         if (MODE == 2 && ck_feed && t + 2 < W) {
             const int xc = t + 2;
             ring[j][xc & 3][q] = ck_n;
-            if (xc + 1 < W) ck_n = ckp[3 * (xc + 1) + q];
+            if (xc + 1 < W) ck_n = ckp[3 * (xc + 1) + q] * mult;
         }
         __syncthreads();
     }
