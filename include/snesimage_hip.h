@@ -114,11 +114,12 @@ typedef struct {
     uint64_t scored, useful;                     /* candidates scored in all; candidates of the calls that took effect */
 } snesimage_run_stats;
 /* n_calls calls from scheduler state (*palette, *index, *channel, *step) — advanced as by snesimage_schedule_next — call j
- * drawing its random candidates from stream (seed, first_step_id + j).  window: calls per launch set (0 = adaptive: doubles
+ * drawing its random candidates from stream (seed, first_step_id + j); n_random = 0: the reference's 64 (lib.rs:205), at most 64
+ * in a window (larger calls are stepped one by one).  window: calls per launch set (0 = adaptive: doubles
  * after a clean window up to SNES_WINDOW_MAX, default 64, falls back to the run length seen; 1 = call by call).
  * log (optional): n_calls records.  stats (optional). */
 int32_t snesimage_run_slots(snesimage_ctx *ctx, uint32_t n_calls, uint64_t seed, uint64_t first_step_id, uint32_t *palette,
-                            uint32_t *index, uint32_t *channel, uint32_t *step, uint32_t window,
+                            uint32_t *index, uint32_t *channel, uint32_t *step, uint32_t n_random, uint32_t window,
                             snesimage_call_result *log, snesimage_run_stats *stats);
 /* Allocate the storage of windows of up to n_slots calls now instead of on first use (about 0.3 GB of HBM per call; the
  * library never takes more than SNES_WINDOW_MAX, default 64, calls per window). */
@@ -156,7 +157,7 @@ int32_t snesimage_group_step(snesimage_group *group, uint32_t method, uint32_t p
  * trajectory (lib.rs:888-933), bit-identical palettes on all devices.  Every member must be in the state
  * snesimage_group_create asks for. */
 int32_t snesimage_group_run_slots(snesimage_group *group, uint32_t n_calls, uint64_t seed, uint64_t first_step_id,
-                                  uint32_t *palette, uint32_t *index, uint32_t *channel, uint32_t *step, uint32_t window,
+                                  uint32_t *palette, uint32_t *index, uint32_t *channel, uint32_t *step, uint32_t n_random, uint32_t window,
                                   snesimage_call_result *log, snesimage_run_stats *stats);
 
 /* Throughput mode — many independent images on one device, one launch per stage of an optimizer call

@@ -55,7 +55,7 @@ SIGNATURES = [
     ("snesimage_step_begin", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                          C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     ("snesimage_step_commit", C.c_int32, [C.c_void_p, C.c_void_p]),
-    ("snesimage_run_slots", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, _u32p, _u32p, _u32p, _u32p, C.c_uint32,
+    ("snesimage_run_slots", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, _u32p, _u32p, _u32p, _u32p, C.c_uint32, C.c_uint32,
                                         C.POINTER(CallResult), C.POINTER(RunStats)]),
     ("snesimage_slots_reserve", C.c_int32, [C.c_void_p, C.c_uint32]),
     ("snesimage_slots_begin", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -65,7 +65,7 @@ SIGNATURES = [
     ("snesimage_group_destroy", None, [C.c_void_p]),
     ("snesimage_group_step", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32,
                                          _f64p, _u8p]),
-    ("snesimage_group_run_slots", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, _u32p, _u32p, _u32p, _u32p, C.c_uint32,
+    ("snesimage_group_run_slots", C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, _u32p, _u32p, _u32p, _u32p, C.c_uint32, C.c_uint32,
                                               C.POINTER(CallResult), C.POINTER(RunStats)]),
     ("snesimage_batch_create", C.c_int32, [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_void_p)]),
     ("snesimage_batch_destroy", None, [C.c_void_p]),

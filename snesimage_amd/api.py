@@ -158,7 +158,7 @@ class OptimizedImage:
         self._chk(self._L.snesimage_last_step(self._c, C.byref(err), _p(best, _ffi._u8p), C.byref(k)))
         return err.value, best, k.value
 
-    def run_slots(self, n_calls, seed=1, first_step_id=0, state=(0, 0, 0, 0), window=0, want_log=True):
+    def run_slots(self, n_calls, seed=1, first_step_id=0, state=(0, 0, 0, 0), window=0, want_log=True, n_random=0):
         """The reference's loop (lib.rs:888-933) for n_calls calls from scheduler state (palette, index, channel, step),
         speculatively several calls per launch (bit-identical to `step` per scheduled call).  Returns (log, state, stats):
         log[j] = (error, best_k, rgb5, changed) after call j."""
@@ -166,7 +166,7 @@ class OptimizedImage:
         log = (_ffi.CallResult * n_calls)() if want_log else None
         stats = _ffi.RunStats()
         self._chk(self._L.snesimage_run_slots(self._c, n_calls, seed, first_step_id, C.byref(st[0]), C.byref(st[1]), C.byref(st[2]),
-                                              C.byref(st[3]), int(window), log, C.byref(stats)))
+                                              C.byref(st[3]), int(n_random), int(window), log, C.byref(stats)))
         out = [(r.error, r.best_k, np.array(r.rgb5[:], np.uint8), int(r.changed)) for r in log] if want_log else None
         return out, tuple(v.value for v in st), {k: getattr(stats, k) for k in ("calls", "accepted", "windows", "voided", "scored", "useful")}
 

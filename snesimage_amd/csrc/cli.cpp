@@ -239,7 +239,7 @@ int main(int argc, char **argv) {
         }
         sweep = step;
     };
-    if (ncand == 64 && window != 1) {
+    if (ncand <= 64 && window != 1) {
         // The reference's loop (src/lib.rs:888-933), several calls per launch: snesimage_run_slots scores the coming calls of the
         // schedule against the current palette and applies them in order up to the first one that changes it — the same
         // trajectory, call for call, as stepping one call at a time (--window 1).  A run ends with its sweep when tiles are
@@ -258,8 +258,8 @@ int main(int argc, char **argv) {
             log.resize(n);
             uint32_t p = palette, ix = index, ch = channel, st = step, method = 0;
             snesimage_run_stats rs{};
-            if ((group ? snesimage_group_run_slots(group, n, seed, call, &palette, &index, &channel, &step, window, log.data(), &rs)
-                       : snesimage_run_slots(ctx, n, seed, call, &palette, &index, &channel, &step, window, log.data(), &rs)) != 0) die(std::string("Unable to optimize palette: ") + snesimage_last_error());
+            if ((group ? snesimage_group_run_slots(group, n, seed, call, &palette, &index, &channel, &step, ncand, window, log.data(), &rs)
+                       : snesimage_run_slots(ctx, n, seed, call, &palette, &index, &channel, &step, ncand, window, log.data(), &rs)) != 0) die(std::string("Unable to optimize palette: ") + snesimage_last_error());
             total.calls += rs.calls; total.accepted += rs.accepted; total.windows += rs.windows; total.scored += rs.scored; total.useful += rs.useful;
             for (uint32_t j = 0; j < n; j++) {
                 const uint32_t cp = p, ci = ix;
