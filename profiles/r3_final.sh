@@ -28,7 +28,7 @@ stats images bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --conf
 TL=kw_commit stats slots profiles/r3_slots.py --converge 100 --calls 960 --window 64 || exit 1
 TL=kw_commit stats slots_dither profiles/r3_slots.py --converge 100 --calls 480 --window 64 --config dither || exit 1
 step "bench"
-t0=$(date +%s.%N); python bench.py > $O/bench_rgb.json 2> $O/bench_rgb.err || exit 1; t1=$(date +%s.%N); echo "default invocation: $(echo "$t1 - $t0" | bc) s" | tee $O/bench_rgb_wall.txt
+t0=$(date +%s); python bench.py > $O/bench_rgb.json 2> $O/bench_rgb.err || exit 1; t1=$(date +%s); echo "default invocation: $((t1 - t0)) s" | tee $O/bench_rgb_wall.txt
 python bench.py --config perceptual --steps 100 --no-config-extras > $O/bench_perceptual.json 2> $O/bench_perceptual.err || exit 1
 python bench.py --config dither --steps 40 --no-config-extras > $O/bench_dither.json 2> $O/bench_dither.err || exit 1
 python bench.py --config images --steps 60 > $O/bench_images.json 2> $O/bench_images.err || exit 1
