@@ -115,8 +115,9 @@ typedef struct {
 } snesimage_run_stats;
 /* n_calls calls from scheduler state (*palette, *index, *channel, *step) — advanced as by snesimage_schedule_next — call j
  * drawing its random candidates from stream (seed, first_step_id + j); n_random = 0: the reference's 64 (lib.rs:205), at most 64
- * in a window (larger calls are stepped one by one).  window: calls per launch set (0 = adaptive: doubles
- * after a clean window up to SNES_WINDOW_MAX, default 64, falls back to the run length seen; 1 = call by call).
+ * in a window (larger calls are stepped one by one).  window: calls per launch set (0 = adaptive: the size that
+ * gets most calls through per unit of time at the acceptance rate of the recent windows, at most SNES_WINDOW_MAX, default 64;
+ * 1 = call by call).
  * log (optional): n_calls records.  stats (optional). */
 int32_t snesimage_run_slots(snesimage_ctx *ctx, uint32_t n_calls, uint64_t seed, uint64_t first_step_id, uint32_t *palette,
                             uint32_t *index, uint32_t *channel, uint32_t *step, uint32_t n_random, uint32_t window,

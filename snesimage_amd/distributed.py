@@ -111,22 +111,26 @@ class HipWindowScorer(HipShardScorer):
 
 
 class WindowPolicy:
-    """Calls per window: twice as many after a window that accepted nothing, else about the run of calls the last one got
-    through (the library's own rule in snesimage_run_slots), at least `lo` per rank."""
+    """Calls per window (the library's own rule in snesimage_run_slots): with acceptance rate p a window of K calls gets
+    (1 - (1 - p)^K) / p of them through before the first acceptance voids the rest and costs about t0 + t1 K / world
+    (t0 / t1 ~ 15); p from the recent windows, older ones fading by 0.85 per window.  Speed only: results do not depend on it."""
 
     def __init__(self, world=1, lo=8, hi=64):
-        self.lo, self.hi = lo * world, hi * world
-        self.k = self.lo
+        self.world, self.lo, self.hi = world, lo * world, hi * world
+        self.calls, self.accepts, self.k = 0.0, 0.0, self.lo
 
     def update(self, taken, consumed, accepted):
-        if not accepted:
-            if taken >= self.k:
-                self.k = min(self.hi, self.k * 2)
-        else:
-            a = self.lo
-            while a < consumed:
-                a *= 2
-            self.k = min(self.hi, a)
+        self.calls = 0.85 * self.calls + consumed
+        self.accepts = 0.85 * self.accepts + accepted
+        p = (self.accepts + 0.5) / (self.calls + 8.0)
+        best, k = -1.0, self.lo
+        while k <= self.hi:
+            rate = (1.0 - (1.0 - p) ** k) / p / (15.0 + k / self.world)
+            if rate > best:
+                best, self.k = rate, k
+            k += (4 if k < 32 * self.world else 8) * self.world
+        if not accepted and consumed == taken:  # a clean window: at least twice as many next
+            self.k = max(self.k, min(2 * taken, self.hi))
 
 
 def sharded_run_slots(scorer, sub_count, sub_size, n_calls, seed=1, first_step_id=0, state=(0, 0, 0, 0), window=0, group=None, nes=False):
