@@ -112,6 +112,7 @@ struct snesimage_ctx {
     // instructions and half the runs per CU — B's own run always, the candidates' while they are few (SNES_DITHER4=0: never;
     // SNES_DITHER4_MAX: most runs per launch that still take it)
     bool dither4 = true; uint32_t dither4_max = 512;
+    bool ditherw = true; // longer lists: one wave per resumed run (k_ditherw) instead of two waves and a ring in LDS (k_dither MODE 2)
     bool dither_rec = true; // resumed runs take B's search result where their dithered target equals B's (SNES_DITHER_REC=0: always search)
     Geom G{};
     BlurK K{};
@@ -161,6 +162,12 @@ struct snesimage_ctx {
         uint8_t *dmaps = nullptr, *dmapsC4 = nullptr; // [lane][cap][W*H] candidates' palette_maps, row-major and C4
         uint8_t *bmap = nullptr, *bmapC4 = nullptr, *bcand = nullptr; unsigned long long *dpack = nullptr; double *ckd = nullptr; uint32_t slot_ci = 0;
         int base_sp = -1, base_si = -1; // slot B was built for (with --dither the pack does not depend on the slot, B does)
+        // B's Floyd-Steinberg run a call ahead: while a call's candidates are scored, B of the scheduler's next slot (lib.rs:881-933
+        // walks the slots in raster order) is dithered on B's stream into the second set of buffers, for the palette as it
+        // stands.  The next call takes it if it is for that slot and the commit in between changed nothing (a flag on the
+        // device: the host does not wait for the commit) — B's run then leaves at once — and dithers B itself otherwise.
+        struct Ahead { uint8_t *bmap = nullptr, *bmapC4 = nullptr, *bcand = nullptr; unsigned long long *dpack = nullptr; double *ckd = nullptr; float *btab = nullptr; int *ok = nullptr;
+                       hipEvent_t ev = nullptr; bool on = true, have = false; int sp = -1, si = -1; unsigned long long epoch = 0; } ahead;
     } sp;
     // step state
     uint8_t *d_cand = nullptr; uint32_t cand_cap = 0;
@@ -184,6 +191,7 @@ struct snesimage_ctx {
 
     // cache keys
     bool tables_valid = false, src_valid = false, inc_valid = false;
+    unsigned long long epoch = 0; bool epoch_by_commit = false; // palette / tile-map generations, and whether the last one came from a commit (see sp.ahead)
     int pack_mode = -1, pack_sp = -1, pack_si = -1; bool pack_valid = false;
     // pending step (split phase)
     uint32_t pend_n = 0, pend_sp = 0, pend_si = 0, pend_method = 0; bool pend = false;
@@ -488,6 +496,14 @@ int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
         HIPCHK(dmalloc(&sp.bmap, c->npx)); HIPCHK(dmalloc(&sp.bmapC4, c->npx)); HIPCHK(dmalloc(&sp.bcand, 64));
         HIPCHK(dmalloc(&sp.dpack, sizeof(unsigned long long) * c->npx));
         HIPCHK(dmalloc(&sp.ckd, sizeof(double) * 3 * c->W * (c->H / 4 + 1)));
+        auto &ah = sp.ahead;
+        dfree(ah.bmap); dfree(ah.bmapC4); dfree(ah.bcand); dfree(ah.dpack); dfree(ah.ckd); dfree(ah.btab); dfree(ah.ok); ah.have = false;
+        if (ah.on && sp.side && c->sub_size > 1) {
+            HIPCHK(dmalloc(&ah.bmap, c->npx)); HIPCHK(dmalloc(&ah.bmapC4, c->npx)); HIPCHK(dmalloc(&ah.bcand, 64)); HIPCHK(dmalloc(&ah.btab, sizeof(float) * 8)); HIPCHK(dmalloc(&ah.ok, sizeof(int)));
+            HIPCHK(dmalloc(&ah.dpack, sizeof(unsigned long long) * c->npx));
+            HIPCHK(dmalloc(&ah.ckd, sizeof(double) * 3 * c->W * (c->H / 4 + 1)));
+            if (!ah.ev) HIPCHK(hipEventCreateWithFlags(&ah.ev, hipEventDisableTiming));
+        }
     }
     HIPCHK(hipStreamSynchronize(c->stream)); // the clears above precede whatever the lanes and B's stream launch next
     sp.cap = need; sp.plist_valid = false;
@@ -529,13 +545,22 @@ int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si) {
             // subpalette (k_dither MODE 1), which records, per pixel, the dithered target and the key a candidate has to beat
             const uint32_t j0 = c->sub_size > 1 ? ((uint32_t)si + 1u) % c->sub_size : (uint32_t)si;
             sp.slot_ci = (uint32_t)(sp_idx * (int)c->sub_size + si);
+            auto &ah = sp.ahead;
+            const int *b_done = nullptr; // device flag: B's run for this slot and palette is in place already
+            if (ah.have && ah.sp == sp_idx && ah.si == si && ah.epoch + 1 == c->epoch && c->epoch_by_commit) {
+                std::swap(sp.bmap, ah.bmap); std::swap(sp.bmapC4, ah.bmapC4); std::swap(sp.dpack, ah.dpack); std::swap(sp.ckd, ah.ckd);
+                hipLaunchKernelGGL(k_ahead_ok, dim3(1), dim3(1), 0, c->stream, c->d_last, ah.ok); // the one commit since: did it keep the palette?
+                HIPCHK(hipStreamWaitEvent(c->stream, ah.ev, 0));
+                b_done = ah.ok;
+            }
+            ah.have = false;
             HIPCHK(hipMemcpyAsync(sp.bcand, c->d_colors + 3 * (size_t)(sp_idx * (int)c->sub_size + (int)j0), 3, hipMemcpyDeviceToDevice, c->stream));
             float *btab = sp.cand_tab + 8 * (size_t)(c->nlanes * sp.cap);
             hipLaunchKernelGGL(k_candidate_tables, dim3(1), dim3(64), 0, c->stream, sp.bcand, 1, c->d_eotf, btab);
             DitherParams Dp{};
             Dp.orig = c->d_orig; Dp.tile_pal = c->d_tile_pal; Dp.pal_rgb8 = c->d_pal_rgb8; Dp.cand_tab = btab; Dp.maps = sp.bmap; Dp.mapsC4 = sp.bmapC4;
             Dp.W = (int)c->W; Dp.H = (int)c->H; Dp.sub_size = (int)c->sub_size; Dp.ncol = c->ncol; Dp.slot_ci = sp.slot_ci;
-            Dp.rec_pack = sp.dpack; Dp.ck_out = sp.ckd; Dp.excl_sub = sp_idx; Dp.excl_si = si; Dp.excl_j0 = (int)j0;
+            Dp.rec_pack = sp.dpack; Dp.ck_out = sp.ckd; Dp.excl_sub = sp_idx; Dp.excl_si = si; Dp.excl_j0 = (int)j0; Dp.skip = b_done;
             if (c->dither4 && c->sub_size == 15) hipLaunchKernelGGL((k_dither4<15, 1>), dim3(1), dim3(512), 0, c->stream, Dp);
             else if (c->dither4) hipLaunchKernelGGL((k_dither4<0, 1>), dim3(1), dim3(512), 0, c->stream, Dp);
             else if (c->sub_size == 15) hipLaunchKernelGGL((k_dither<false, 15, 1>), dim3(1), dim3(128), 0, c->stream, Dp);
@@ -565,6 +590,25 @@ int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si) {
         if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_v_base_narrow, dim3(3, (unsigned)(G.nscales - P.s_first)), dim3(256), 0, bs, P);
         HIPCHK(hipGetLastError());
         if (sp.side) HIPCHK(hipEventRecord(sp.ev_base_narrow, bs));
+        if (c->dither && sp.side && sp.ahead.dpack) { // B of the scheduler's next slot, behind this B's sweeps on their stream
+            auto &ah = sp.ahead;
+            int ni = si + 1, np = sp_idx;
+            if (ni == (int)c->sub_size) { ni = 0; np = (np + 1) % (int)c->sub_count; }
+            const int nj0 = (ni + 1) % (int)c->sub_size;
+            HIPCHK(hipMemcpyAsync(ah.bcand, c->d_colors + 3 * (size_t)(np * (int)c->sub_size + nj0), 3, hipMemcpyDeviceToDevice, bs));
+            hipLaunchKernelGGL(k_candidate_tables, dim3(1), dim3(64), 0, bs, ah.bcand, 1, c->d_eotf, ah.btab);
+            DitherParams Dn{};
+            Dn.orig = c->d_orig; Dn.tile_pal = c->d_tile_pal; Dn.pal_rgb8 = c->d_pal_rgb8; Dn.cand_tab = ah.btab; Dn.maps = ah.bmap; Dn.mapsC4 = ah.bmapC4;
+            Dn.W = (int)c->W; Dn.H = (int)c->H; Dn.sub_size = (int)c->sub_size; Dn.ncol = c->ncol; Dn.slot_ci = (uint32_t)(np * (int)c->sub_size + ni);
+            Dn.rec_pack = ah.dpack; Dn.ck_out = ah.ckd; Dn.excl_sub = np; Dn.excl_si = ni; Dn.excl_j0 = nj0;
+            if (c->dither4 && c->sub_size == 15) hipLaunchKernelGGL((k_dither4<15, 1>), dim3(1), dim3(512), 0, bs, Dn);
+            else if (c->dither4) hipLaunchKernelGGL((k_dither4<0, 1>), dim3(1), dim3(512), 0, bs, Dn);
+            else if (c->sub_size == 15) hipLaunchKernelGGL((k_dither<false, 15, 1>), dim3(1), dim3(128), 0, bs, Dn);
+            else hipLaunchKernelGGL((k_dither<false, 0, 1>), dim3(1), dim3(128), 0, bs, Dn);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(ah.ev, bs));
+            ah.have = true; ah.sp = np; ah.si = ni; ah.epoch = c->epoch;
+        }
         sp.plist_valid = true;
     }
     return SNES_OK;
@@ -590,6 +634,8 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
         }
         if (c->dither4 && nc <= c->dither4_max && c->sub_size == 15) hipLaunchKernelGGL((k_dither4<15, 2>), dim3(nc), dim3(512), 0, stream, Dp);
         else if (c->dither4 && nc <= c->dither4_max) hipLaunchKernelGGL((k_dither4<0, 2>), dim3(nc), dim3(512), 0, stream, Dp);
+        else if (c->ditherw && c->sub_size == 15) hipLaunchKernelGGL((k_ditherw<15>), dim3((nc + 3) / 4), dim3(256), 0, stream, Dp, (int)nc);
+        else if (c->ditherw && c->sub_size > 1) hipLaunchKernelGGL((k_ditherw<0>), dim3((nc + 3) / 4), dim3(256), 0, stream, Dp, (int)nc);
         else if (c->sub_size == 15) hipLaunchKernelGGL((k_dither<false, 15, 2>), dim3(nc), dim3(128), 0, stream, Dp);
         else hipLaunchKernelGGL((k_dither<false, 0, 2>), dim3(nc), dim3(128), 0, stream, Dp);
         hipLaunchKernelGGL(k_dither_diff, dim3((nc + 3) / 4), dim3(1024), 0, stream, P); // changed groups = where the maps differ
@@ -791,7 +837,7 @@ int32_t commit(snesimage_ctx *c, const double *d_errors, uint32_t n, uint32_t me
     hipLaunchKernelGGL(k_commit, dim3(1), dim3(256), 0, c->stream, d_errors, (int)n, c->d_cand, c->d_colors, (int)(palette * c->sub_size + index), method == SNES_METHOD_NES ? 1 : 0, c->d_inc_err,
                        c->d_last, T);
     HIPCHK(hipGetLastError());
-    c->pack_valid = false;
+    c->pack_valid = false; c->epoch++; c->epoch_by_commit = true;
     const bool was_synced = c->map_synced;
     if (!c->dither) {
         // lib.rs:237 / 281 / 325 (and :906) re-run optimize() on the committed palette.  Nothing in the optimizer loop reads
@@ -851,6 +897,8 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     if (const char *e = getenv("SNES_LPT")) c->sp.lpt = atoi(e) != 0;
     if (const char *e = getenv("SNES_DOWN1")) c->sp.down1 = atoi(e) != 0;
     if (const char *e = getenv("SNES_DITHER4")) c->dither4 = atoi(e) != 0;
+    if (const char *e = getenv("SNES_DITHERW")) c->ditherw = atoi(e) != 0;
+    if (const char *e = getenv("SNES_DITHER_AHEAD")) c->sp.ahead.on = atoi(e) != 0;
     if (const char *e = getenv("SNES_DITHER_REC")) c->dither_rec = atoi(e) != 0;
     if (const char *e = getenv("SNES_DITHER4_MAX")) { int v = atoi(e); if (v >= 0) c->dither4_max = (uint32_t)v; }
     if (const char *e = getenv("SNES_H2Q_MAX")) { int v = atoi(e); if (v >= 0) c->sp.h2q_max = (uint32_t)v; }
@@ -953,7 +1001,8 @@ void snesimage_destroy(snesimage_ctx *c) {
     for (auto &L : c->extra) { if (L.stream) (void)hipStreamSynchronize(L.stream); dfree(L.d_mapsC4); dfree(L.d_mapsR4); dfree(L.d_work); dfree(L.d_cand_tab); dfree(L.d_cand_lab); dfree(L.d_part); dfree(L.d_maps); dfree(L.d_mapsT); if (L.done) (void)hipEventDestroy(L.done); if (L.stream) (void)hipStreamDestroy(L.stream); }
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
     { auto &q = c->sp; if (q.base_stream) { (void)hipStreamSynchronize(q.base_stream); (void)hipStreamDestroy(q.base_stream); (void)hipEventDestroy(q.ev_base_in); (void)hipEventDestroy(q.ev_base_h); (void)hipEventDestroy(q.ev_base_narrow); (void)hipEventDestroy(q.ev_base_done); } dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.order); dfree(q.first); dfree(q.cand_lab); dfree(q.bitmap); dfree(q.ckh);
-      dfree(q.dmaps); dfree(q.dmapsC4); dfree(q.bmap); dfree(q.bmapC4); dfree(q.bcand); dfree(q.dpack); dfree(q.ckd); }
+      dfree(q.dmaps); dfree(q.dmapsC4); dfree(q.bmap); dfree(q.bmapC4); dfree(q.bcand); dfree(q.dpack); dfree(q.ckd);
+      dfree(q.ahead.bmap); dfree(q.ahead.bmapC4); dfree(q.ahead.bcand); dfree(q.ahead.dpack); dfree(q.ahead.ckd); dfree(q.ahead.btab); dfree(q.ahead.ok); if (q.ahead.ev) (void)hipEventDestroy(q.ahead.ev); }
     kmeans_free(c->km);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -1139,7 +1188,7 @@ int32_t snesimage_set_tile_palettes(snesimage_ctx *c, const uint8_t *in) {
     CHECK(ensure_map(c)); // the owed optimize() belongs to the state before this change
     HIPCHK(hipMemcpyAsync(c->d_tile_pal, in, 1024, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->pack_valid = false; c->inc_valid = false; c->map_synced = false;
+    c->pack_valid = false; c->inc_valid = false; c->map_synced = false; c->epoch++; c->epoch_by_commit = false;
     return SNES_OK;
 }
 int32_t snesimage_get_palette_rgb5(snesimage_ctx *c, uint8_t *out) {
@@ -1155,7 +1204,7 @@ int32_t snesimage_set_palette_rgb5(snesimage_ctx *c, const uint8_t *in) {
     CHECK(ensure_map(c));
     HIPCHK(hipMemcpyAsync(c->d_colors, in, 3 * (size_t)c->ncol, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->tables_valid = false; c->pack_valid = false; c->inc_valid = false; c->map_synced = false;
+    c->tables_valid = false; c->pack_valid = false; c->inc_valid = false; c->map_synced = false; c->epoch++; c->epoch_by_commit = false;
     return SNES_OK;
 }
 int32_t snesimage_get_palette_u16(snesimage_ctx *c, uint16_t *out) {
@@ -1180,7 +1229,7 @@ int32_t snesimage_set_palette_map(snesimage_ctx *c, const uint8_t *in) {
     c->map_pending = false; // replaced wholesale
     HIPCHK(hipMemcpyAsync(c->d_map, in, c->npx, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->pack_valid = false; c->inc_valid = false; c->map_synced = false;
+    c->pack_valid = false; c->inc_valid = false; c->map_synced = false; c->epoch++; c->epoch_by_commit = false;
     return SNES_OK;
 }
 
@@ -1294,7 +1343,7 @@ int32_t snesimage_reassign_tiles(snesimage_ctx *c, uint32_t *moved_out) {
     HIPCHK(hipMemcpyAsync(&moved, c->d_tile_moved, sizeof(moved), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (moved) { // as after snesimage_set_tile_palettes, then optimize() (the palettes are kept)
-        c->pack_valid = false; c->inc_valid = false; c->map_synced = false;
+        c->pack_valid = false; c->inc_valid = false; c->map_synced = false; c->epoch++; c->epoch_by_commit = false;
         CHECK(do_optimize(c));
         HIPCHK(hipStreamSynchronize(c->stream));
     }

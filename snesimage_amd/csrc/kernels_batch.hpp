@@ -55,6 +55,7 @@ template <int SUB> __global__ __launch_bounds__(512) void kb_dither_base(const B
 __global__ __launch_bounds__(1024) void kb_dither_first(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; dither_first_body(a.Pc); }
 template <int SUB> __global__ __launch_bounds__(512) void kb_dither_run4(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; if ((int)blockIdx.x < a.n) dither4_body<SUB, 2>(a.Dc, (int)blockIdx.x); }
 template <int SUB> __global__ __launch_bounds__(128) void kb_dither_run(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; if ((int)blockIdx.x < a.n) dither_body<false, SUB, 2>(a.Dc, (int)blockIdx.x); }
+template <int SUB> __global__ __launch_bounds__(256) void kb_dither_runw(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; ditherw_body<SUB>(a.Dc, (int)blockIdx.x, a.n); }
 __global__ __launch_bounds__(1024) void kb_dither_diff(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; dither_diff_body(a.Pc); }
 __global__ __launch_bounds__(1024) void kb_sparse_scan(const BatchArgs *__restrict__ A, int base, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_scan_body(base ? a.Pb : a.Pc); }
 __global__ __launch_bounds__(256) void kb_base_down(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; base_down_body(a.Pb); }

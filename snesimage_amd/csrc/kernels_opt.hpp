@@ -453,6 +453,194 @@ __device__ __forceinline__ void dither4_body(const DitherParams &P, const int bl
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Resumed runs (MODE 2, RGB distance), one WAVE per run: lane j owns rows y0 + j, y0 + j + 64, ...  With thousands of runs
+// in a launch the chip is short of issue slots and of waves to hide a step's latency behind, not of parallelism inside a
+// run, and k_dither's 128 rows in flight cost it two waves that meet at a barrier every step, a 12 KB ring in LDS per run
+// and — for a run of r rows — 2 (min(r,128) - 1) + 256 ceil(r / 128) steps of both waves.  Here
+//  * the row above is the lane below: v(x+1, y-1) * 0.8 arrives over DPP (wave_shr:1) one step after lane j-1 formed it,
+//    and the lane keeps the three columns it needs in registers; no ring, no barrier after the table is loaded;
+//  * lane 0's row above is lane 63's row of the previous pass, 130 steps earlier: a 256-column buffer in LDS per wave,
+//    written by lane 63 alone (LDS operations of one wave execute in order) and prefilled with B's checkpoint row;
+//  * the four runs of a block share one entry table: the slot's entry holds the colour of its stand-in j0 as in B's
+//    own run (MODE 1 above), the search returns the best OTHER entry and its key, and the run's own colour is one more
+//    key from registers, compared under the same rule (lowest key, then lowest index): the same choice as a search of a
+//    table holding the run's colour.  B's record replaces the search where the run's dithered target rounds to B's.
+// 2 * 63 + 256 ceil(r / 64) steps of one wave for a run of r rows: 30 % fewer wave-steps over resume rows drawn evenly,
+// 29 KB of LDS per four runs.  The border cases multiply by a weight of zero instead of skipping the addition: every
+// value is finite, the sums start at +0.0 and (+0.0) + (-0.0) = +0.0, so the diffused error is bit for bit the one above.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double dpp_up(double wrap, double mine) { // lane j: lane j-1's `mine`; lane 0: `wrap`
+    const uint64_t w = (uint64_t)__double_as_longlong(wrap), m = (uint64_t)__double_as_longlong(mine);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)w, (int)(uint32_t)m, 0x138, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(w >> 32), (int)(uint32_t)(m >> 32), 0x138, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+template <int SUB>
+__device__ __forceinline__ void ditherw_body(const DitherParams &P, const int blk, const int nrun) {
+    constexpr int W = 256, RW = 4; // runs (waves) per block
+    __shared__ uint4 s_ent[256];
+    __shared__ uint8_t s_tile[1024];
+    __shared__ double s_wrap[RW][W][3];
+    if (P.skip && *P.skip) return;
+    const int tid = threadIdx.x, wv = tid >> 6, j = tid & 63;
+    const int H = P.H;
+    const int sub_size = SUB ? SUB : P.sub_size; // >= 2: a one-entry subpalette has no stand-in (the caller keeps k_dither for it)
+    const int slot_sub = (int)P.slot_ci / sub_size, slot_si = (int)P.slot_ci - slot_sub * sub_size, slot_j0 = (slot_si + 1) % sub_size;
+    for (int i = tid; i < P.ncol; i += 64 * RW) {
+        const uint32_t c = P.pal_rgb8[(uint32_t)i == P.slot_ci ? slot_sub * sub_size + slot_j0 : i];
+        const uint32_t r = c & 0xff, g = (c >> 8) & 0xff, b = (c >> 16) & 0xff;
+        s_ent[i] = make_uint4(r | (b << 16), (8u * (1024u + r)) | ((8u * (1534u - r)) << 16), g, c);
+    }
+    for (int i = tid; i < 1024; i += 64 * RW) s_tile[i] = P.tile_pal[i];
+    __syncthreads(); // the only one: from here on the waves go their own ways
+    const int run = blk * RW + wv;
+    if (run >= nrun) return;
+    const int cand = P.order ? P.order[run] : run;
+    uint4 own; // the run's colour, as a table entry
+    { const uint32_t c = __float_as_uint(P.cand_tab[8 * (size_t)cand + 6]); const uint32_t r = c & 0xff, g = (c >> 8) & 0xff, b = (c >> 16) & 0xff;
+      own = make_uint4(r | (b << 16), (8u * (1024u + r)) | ((8u * (1534u - r)) << 16), g, c); }
+    const double w0 = 7.0 / 16.0, w1 = 3.0 / 16.0, w2 = 5.0 / 16.0, w3 = 1.0 / 16.0, mult = 0.8;
+    uint8_t *map = P.maps + (size_t)cand * W * H;
+    uint32_t *map4 = reinterpret_cast<uint32_t *>(map);
+    uint32_t *mapC4 = P.mapsC4 ? reinterpret_cast<uint32_t *>(P.mapsC4 + (size_t)cand * W * H) : nullptr;
+    const int g0 = P.first_group[P.first_k0 + cand];
+    const int y0 = min(4 * g0, H);
+    { // rows above are B's
+        const uint32_t *b4 = reinterpret_cast<const uint32_t *>(P.bmap), *bC4 = reinterpret_cast<const uint32_t *>(P.bmapC4);
+        for (int i = j; i < y0 * (W >> 2); i += 64) map4[i] = b4[i];
+        if (mapC4) for (int i = j; i < y0 * (W >> 2); i += 64) { const int q = i / y0, yy = i - q * y0; mapC4[q * H + yy] = bC4[q * H + yy]; }
+        if (y0 >= H) return;
+    }
+    double (*wrap)[3] = s_wrap[wv];
+    { // row y0 - 1: B's checkpoint of the group (times 0.8, as every value on its way down), or nothing above row 0
+        const double *ckp = P.ck_in + (size_t)(y0 >> 2) * W * 3;
+        for (int i = j; i < W * 3; i += 64) (&wrap[0][0])[i] = y0 > 0 ? ckp[i] * mult : 0.0;
+    }
+    const int nrows = H - y0;
+    const int passes = (nrows + 63) >> 6;
+    const int nth = nrows < 64 ? nrows : 64;
+    const int total_steps = 2 * (nth - 1) + passes * W;
+    double left[3] = {0.0, 0.0, 0.0}; // v(x-1, y) * 0.8; after the step, the value the lane above... below fetches
+    double u[3][3];                   // [age][channel]: the row above at columns x-1, x, x+1 (rotating: see the loop)
+#pragma unroll
+    for (int a = 0; a < 3; a++) { u[a][0] = 0.0; u[a][1] = 0.0; u[a][2] = 0.0; }
+    double wnx[3] = {wrap[0][0], wrap[0][1], wrap[0][2]}; // lane 0's row above, column (t + 1) & 255, read a step ahead: column 0 for the step before the first
+    uint32_t macc = 0;
+    const uint4 *orig4 = reinterpret_cast<const uint4 *>(P.orig);
+    uint4 o_cur = make_uint4(0, 0, 0, 0), o_nxt = (y0 + j < H) ? orig4[(size_t)(y0 + j) * (W >> 2)] : make_uint4(0, 0, 0, 0);
+    const bool use_rec = P.rec_in != nullptr;
+    const uint4 *rec4 = reinterpret_cast<const uint4 *>(P.rec_in);
+    uint4 ra_cur = make_uint4(0, 0, 0, 0), rb_cur = ra_cur, ra_nxt = ra_cur, rb_nxt = ra_cur;
+    if (use_rec && y0 + j < H) { ra_nxt = rec4[(size_t)(y0 + j) * (W >> 1)]; rb_nxt = rec4[(size_t)(y0 + j) * (W >> 1) + 1]; }
+    // Before step t lane j holds columns x-1, x of the row above and fetches x+1 = what lane j-1 formed in step t-1.  The
+    // lane's first step is t = 2j; it has shifted through the steps before (the row above started two steps earlier).
+    // One "step before the first" hands column 0 to the lanes' registers: lane j-1's `left` is still zero then, which is
+    // right for every lane but lane 0 — whose row above is in `wrap` — so the loop starts at t = -1 with nothing active.
+    for (int t3 = -1; t3 < total_steps; t3 += 3) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int t = t3 + k;
+            // u[(k+2)%3] <- column x+1 of the row above; u[k%3] is x-1, u[(k+1)%3] is x   (k = t + 1 mod 3)
+            double *um = u[k % 3], *uc = u[(k + 1) % 3], *up = u[(k + 2) % 3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) up[c] = dpp_up(wnx[c], left[c]);
+            { const double *wn = wrap[(t + 2) & (W - 1)]; wnx[0] = wn[0]; wnx[1] = wn[1]; wnx[2] = wn[2]; } // for the next step
+            const int local = t - 2 * j;
+            const int x = local & (W - 1), pass = local >> 8, y = y0 + j + 64 * pass;
+            const bool act = t >= 0 && t < total_steps && local >= 0 && pass < passes && y < H;
+            if (act) {
+                const int base = (int)s_tile[(x >> 3) + (y >> 3) * (W >> 3)] * sub_size;
+                if ((x & 3) == 0) {
+                    o_cur = o_nxt;
+                    const int ln = local + 4;
+                    const int xn = ln & (W - 1), yn = y0 + j + 64 * (ln >> 8);
+                    const bool more = (ln >> 8) < passes && yn < H;
+                    if (more) o_nxt = orig4[((size_t)yn * W + xn) >> 2];
+                    if (use_rec) {
+                        ra_cur = ra_nxt; rb_cur = rb_nxt;
+                        if (more) { const size_t q2 = ((size_t)yn * W + xn) >> 1; ra_nxt = rec4[q2]; rb_nxt = rec4[q2 + 1]; }
+                    }
+                }
+                const uint32_t o = (x & 2) ? ((x & 1) ? o_cur.w : o_cur.z) : ((x & 1) ? o_cur.y : o_cur.x);
+                const bool opaque = (o >> 24) != 0;
+                // (no row above row 0: `wrap` and the registers hold zeros there)
+                const double w3x = x > 0 ? w3 : 0.0, w1x = x + 1 < W ? w1 : 0.0, w0x = x > 0 ? w0 : 0.0;
+                double e[3], target[3];
+                uint32_t tq[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    double acc = 0.0;
+                    acc = acc + um[c] * w3x;
+                    acc = acc + uc[c] * w2;
+                    acc = acc + up[c] * w1x;
+                    acc = acc + left[c] * w0x;
+                    e[c] = acc;
+                    target[c] = (double)((o >> (8 * c)) & 0xff) + acc;
+                    const double cl = fmin(fmax(target[c], 0.0), 255.0);
+                    const double tr = trunc(cl); // Rust f64::round: half away from zero (cl >= 0)
+                    tq[c] = (uint32_t)(tr + ((cl - tr >= 0.5) ? 1.0 : 0.0));
+                }
+                const uint32_t t1 = tq[0] | (tq[2] << 16), tw = (8u * tq[0]) | ((0u - 8u * tq[0]) << 16);
+                const int tg = (int)tq[1];
+                const bool in_sub = base == slot_sub * sub_size;
+                int best = 0;        // the best entry other than the slot's
+                uint32_t thr = 0;    // the run's colour takes the pixel iff its key is below
+                bool searched = false;
+                if (use_rec) {
+                    const uint32_t rlo = (x & 2) ? ((x & 1) ? rb_cur.z : rb_cur.x) : ((x & 1) ? ra_cur.z : ra_cur.x);
+                    const uint32_t rhi = (x & 2) ? ((x & 1) ? rb_cur.w : rb_cur.y) : ((x & 1) ? ra_cur.w : ra_cur.y);
+                    const bool same = (rlo & 0x00ffffffu) == (tq[0] | (tq[1] << 8) | (tq[2] << 16));
+                    if (!__any(!same)) { best = opaque ? (int)(rlo >> 24) - base : 0; thr = rhi; searched = true; }
+                }
+                if (!searched) {
+                    uint32_t bk = 0xffffffffu; int bbase = 0;
+                    if (SUB) {
+#pragma unroll
+                        for (int i0 = 0; i0 < SUB; i0 += 8) {
+                            const uint32_t g = (SUB - i0 >= 8) ? dither_group_min<8>(s_ent + base + i0, t1, tw, tg)
+                                                               : dither_group_min<(SUB & 7) ? (SUB & 7) : 8>(s_ent + base + i0, t1, tw, tg);
+                            if (i0 == 0 || (g >> 3) < (bk >> 3)) { bk = g; bbase = i0; }
+                        }
+                        best = bbase + (int)(bk & 7);
+                        bk >>= 3;
+                    } else {
+                        int i0 = 0;
+                        for (; i0 + 8 <= sub_size; i0 += 8) {
+                            const uint32_t g = dither_group_min<8>(s_ent + base + i0, t1, tw, tg);
+                            if (i0 == 0 || (g >> 3) < (bk >> 3)) { bk = g; bbase = i0; }
+                        }
+                        best = bbase + (int)(bk & 7);
+                        bk >>= 3;
+                        for (; i0 < sub_size; i0++) { // ragged tail, one entry at a time
+                            const uint32_t g = dither_group_min<1>(s_ent + base + i0, t1, tw, tg) >> 3;
+                            if (i0 == 0 || g < bk) { bk = g; best = i0; }
+                        }
+                    }
+                    if (in_sub && best == slot_si) best = slot_j0; // the stand-in was found under the slot's index
+                    thr = (in_sub && opaque) ? bk + (slot_si < best ? 1u : 0u) : 0u;
+                }
+                const uint32_t kc = dither_group_min<1>(&own, t1, tw, tg) >> 3;
+                const bool mine = kc < thr;
+                const uint32_t nc = mine ? own.w : s_ent[base + best].w;
+                const uint8_t m = opaque ? (uint8_t)(mine ? slot_si : best) : 0;
+                macc = (macc >> 8) | ((uint32_t)m << 24);
+                if ((x & 3) == 3) {
+                    const size_t px = (size_t)y * W + x;
+                    map4[px >> 2] = macc;
+                    if (mapC4) mapC4[idx_c4(x & ~3, y, H) >> 2] = macc;
+                }
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const double d = target[c] - (double)((nc >> (8 * c)) & 0xff);
+                    left[c] = (opaque ? d : e[c]) * mult; // transparent pixels forward their incoming error (lib.rs:469-474)
+                }
+                if (j == 63) { wrap[x][0] = left[0]; wrap[x][1] = left[1]; wrap[x][2] = left[2]; } // the row above lane 0's next pass
+            }
+        }
+    }
+}
+
 // ---- the winner's map -----------------------------------------------------------------------------------
 // Each lane remembers the first-lowest error it has scored in the current candidate list and that candidate's map.
 struct BestRec { double err; int k; int pad; };
@@ -485,6 +673,8 @@ __global__ __launch_bounds__(1024) void k_keep_best(const double *__restrict__ e
     __syncthreads(); // every thread has compared against the old record
     if (t == 0) { rec->err = be; rec->k = off + bi * stride; }
 }
+// sp.ahead (capi.hip): B's Floyd-Steinberg run for this call was made during the previous one; it stands iff that call's commit kept the palette
+__global__ void k_ahead_ok(const StepResult *__restrict__ last, int *__restrict__ ok) { *ok = last->changed ? 0 : 1; }
 // After k_commit: if the winner was scored here, its map becomes the image's map and *skip = 1 (the re-dither is void);
 // likewise when nothing was accepted and the stored map already belongs to the palette.
 __global__ __launch_bounds__(1024) void k_take_best_map(const StepResult *__restrict__ last, const BestRec *__restrict__ recs, int nrec, const uint8_t *__restrict__ bestmaps, int npx,
@@ -852,6 +1042,8 @@ template <bool PERC, int SUB, int MODE = 0, int NT = 128>
 __global__ __launch_bounds__(NT) void k_dither(DitherParams P) { dither_body<PERC, SUB, MODE, NT>(P, (int)blockIdx.x); }
 template <int SUB, int MODE>
 __global__ __launch_bounds__(512) void k_dither4(DitherParams P) { dither4_body<SUB, MODE>(P, (int)blockIdx.x); }
+template <int SUB>
+__global__ __launch_bounds__(256) void k_ditherw(DitherParams P, int nrun) { ditherw_body<SUB>(P, (int)blockIdx.x, nrun); }
 __global__ void k_gen_candidates(int method, int n, unsigned long long key, const uint8_t *__restrict__ colors, int slot, int channel, uint8_t *__restrict__ cand,
                                  int rank = 0, int count = 1, uint8_t *__restrict__ sel = nullptr, double *__restrict__ errors = nullptr) {
     gen_candidates_body(method, n, key, colors, slot, channel, cand, rank, count, sel, errors);

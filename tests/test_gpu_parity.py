@@ -694,6 +694,78 @@ def test_resumed_dither_equals_full_dither(S, O, seed, variant, monkeypatch):
     sparse.close()
 
 
+@pytest.mark.parametrize("sub_count,sub_size", [(8, 15), (5, 7)])
+def test_long_dither_lists_one_wave_per_run(S, img256_alpha, sub_count, sub_size, monkeypatch):
+    """Lists of more than 512 candidates resume their Floyd-Steinberg runs one wave per run (k_ditherw: the row above over
+    DPP, a shared entry table with the slot's stand-in, the run's own colour from registers) — against the round-1 path
+    (every candidate dithered from row 0 by k_dither, dense scoring) bit for bit, with the unrolled 15-entry search and
+    the generic one, on an image with transparent pixels; and k_ditherw against the two-wave k_dither (SNES_DITHERW=0)."""
+    monkeypatch.setenv("SNES_SPARSE", "0")
+    dense = S.OptimizedImage(img256_alpha, sub_count, sub_size, dither=True)
+    monkeypatch.delenv("SNES_SPARSE")
+    wave = S.OptimizedImage(img256_alpha, sub_count, sub_size, dither=True)
+    monkeypatch.setenv("SNES_DITHERW", "0")
+    ring = S.OptimizedImage(img256_alpha, sub_count, sub_size, dither=True)
+    monkeypatch.delenv("SNES_DITHERW")
+    dense.initialize_tiles()
+    dense.recalculate_palettes()
+    for im in (wave, ring):
+        im.tile_palettes = dense.tile_palettes
+        im.palette = dense.palette
+        im.optimize()
+    pal = dense.palette
+    for slot in [(0, 0), (sub_count - 1, sub_size - 1), (2, 3)]:
+        ci = slot[0] * sub_size + slot[1]
+        cand = S.random_candidates(77, ci, 700)
+        cand[0] = pal[ci]
+        cand[1] = pal[slot[0] * sub_size + (slot[1] + 1) % sub_size]
+        cand[2] = [0, 0, 0]
+        cand[3] = [31, 31, 31]
+        ed = dense.score_candidates(slot[0], slot[1], cand)
+        ew = wave.score_candidates(slot[0], slot[1], cand)
+        er = ring.score_candidates(slot[0], slot[1], cand)
+        assert np.array_equal(ed, ew), (slot, int(np.argmax(ed != ew)), float(np.max(np.abs(ed - ew))))
+        assert np.array_equal(ew, er)
+    e_d, b_d = dense.step(S.METHOD_RANDOM, 1, 2, 0, 9, 0, 640)
+    e_w, b_w = wave.step(S.METHOD_RANDOM, 1, 2, 0, 9, 0, 640)
+    assert e_d == e_w and np.array_equal(b_d, b_w) and np.array_equal(dense.palette_map, wave.palette_map)
+    for im in (dense, wave, ring):
+        im.close()
+
+
+def test_dither_base_image_a_call_ahead(S, monkeypatch):
+    """--dither, call by call: B of the scheduler's next slot is dithered on the side stream during a call and taken by the
+    next call iff the commit in between kept the palette (a device flag).  A run over consecutive slots — accepted and
+    rejected calls mixed, a call on an unexpected slot, a palette written from outside — equals the run without it."""
+    from snesimage_amd.synth import synth_image
+    img = synth_image(0x5EED0004)
+    ahead = S.OptimizedImage(img, 8, 15, dither=True)
+    monkeypatch.setenv("SNES_DITHER_AHEAD", "0")
+    plain = S.OptimizedImage(img, 8, 15, dither=True)
+    monkeypatch.delenv("SNES_DITHER_AHEAD")
+    plain.initialize_tiles()
+    plain.recalculate_palettes()
+    ahead.tile_palettes = plain.tile_palettes
+    ahead.palette = plain.palette
+    ahead.optimize()
+    plain.optimize()
+    calls = S.schedule(8, 15, 40)
+    order = [(p, i) for (_, p, i, _, _) in calls[:30]] + [(5, 5), (5, 6), (5, 7), (0, 0), (0, 1)]
+    for k, (p, i) in enumerate(order):
+        if k == 20:  # the palette changes behind the optimizer's back: the B made ahead is void
+            pal = plain.palette.copy()
+            pal[17] = [3, 30, 9]
+            plain.palette = pal
+            ahead.palette = pal
+        e_p, b_p = plain.step(S.METHOD_RANDOM, p, i, 0, 5, k, 96)
+        e_a, b_a = ahead.step(S.METHOD_RANDOM, p, i, 0, 5, k, 96)
+        assert e_p == e_a and np.array_equal(b_p, b_a), k
+    assert np.array_equal(plain.palette, ahead.palette) and np.array_equal(plain.palette_map, ahead.palette_map)
+    assert plain.error() == ahead.error()
+    plain.close()
+    ahead.close()
+
+
 @pytest.mark.parametrize("flags", [{}, {"perceptual": True}, {"dither": True}])
 def test_reassign_tiles_matches_oracle(S, O, img256_alpha, flags):
     """snesimage_reassign_tiles (not in the reference: TODO.md:36-37): tiles moved, tile_palettes, palette_map and error
