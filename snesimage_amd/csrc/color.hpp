@@ -87,6 +87,34 @@ SNES_HD float ciede_hprime(float b, float ap) {
 // pixel in lightness by far more than the pixel's current error most of the time: this spares ~85 % of the evaluations.
 SNES_HD bool ciede2000_cannot_beat(const Lab &c1, const Lab &c2, float bound) { return fabsf(c1.l - c2.l) > 1.752f * bound; }
 
+// A second sure "no", on lightness and the a-b plane together.  With t_C = dC'/S_C and t_H = dH'/S_H,
+//   t_C^2 + t_H^2 + R_T t_C t_H >= (1 - |R_T| / 2) (t_C^2 + t_H^2)                    (|t_C t_H| <= half the sum of squares)
+//   t_C^2 + t_H^2 >= (dC'^2 + dH'^2) / max(S_C, S_H)^2,   dC'^2 + dH'^2 = da'^2 + db^2 >= da^2 + db^2
+// (the law of cosines with dH' = 2 sqrt(C1' C2') sin(dh'/2); a' = (1 + G) a with the same G in [0, 0.5] on both sides),
+//   S_C = 1 + 0.045 Cm', S_H = 1 + 0.015 Cm' T <= 1 + 0.029 Cm' (T <= 1.93), Cm' <= 1.5 (C1 + C2) / 2,
+//   |R_T| = R_C |sin(2 dtheta)| <= 0.8661 R_C (2 dtheta <= 60 degrees), R_C increasing in Cm',
+// so dE00^2 >= (dL / 1.7471)^2 + (1 - 0.8661 R_C(0.75 s) / 2) (da^2 + db^2) / (1 + 0.03375 s)^2, s = C1 + C2.  Every
+// constant below is rounded to the safe side and the bound is raised by 0.5 % and 1e-3 before the comparison (the f32
+// evaluation of the formula itself is good to ~1e-4 absolute at worst, where C' or h' cancel): whenever this returns true
+// the computed distance is strictly above `bound`.  Of the pixels the lightness test lets through, this rules out
+// most: a random candidate colour is far from a pixel in chroma more often than it is near.
+SNES_HD bool ciede2000_cannot_beat_ab(const Lab &c1, float ch1, const Lab &c2, float bound) {
+    const float ch2 = sqrtf(c2.a * c2.a + c2.b * c2.b);
+    const float s = ch1 + ch2, u = 0.7501f * s;
+    const float u2 = u * u, u4 = u2 * u2, u7 = (u * u2) * u4;
+    const float dl = c1.l - c2.l, da = c1.a - c2.a, db = c1.b - c2.b;
+    const float sm = 1.0f + 0.03376f * s;
+#ifdef __HIP_DEVICE_COMPILE__
+    const float rcq = sqrtf(__fdividef(u7, u7 + 6103515625.0f)) * 1.0001f; // R_C / 2 (fast division: within the margins)
+    const float lb2 = 0.3257f * dl * dl + __fdividef((1.0f - 0.8661f * rcq) * (da * da + db * db), sm * sm * 1.0001f);
+#else
+    const float rcq = sqrtf(u7 / (u7 + 6103515625.0f)) * 1.0001f;
+    const float lb2 = 0.3257f * dl * dl + (1.0f - 0.8661f * rcq) * (da * da + db * db) / (sm * sm * 1.0001f);
+#endif
+    const float b = 1.005f * bound + 1e-3f;
+    return lb2 > b * b;
+}
+
 // palette::color_difference::Ciede2000 for Lab<_, f32>, kL = kC = kH = 1
 SNES_HD float ciede2000(Lab c1, Lab c2) {
     const float pi_over_180 = (float)(3.14159265358979323846 / 180.0);

@@ -68,9 +68,11 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
 
 // RGB nearest entry among n (<= 8) consecutive table rows: 8*red_mean_key + u for row u, so the smallest value is the
-// first minimal key.  Per entry the table holds {r | b<<16, 8*(1024+r) | 8*(1534-r)<<16, g, rgb8}; with the target's
-// {r | b<<16, 8r | (-8r)<<16, g} one key is three packed 16-bit ops (differences, their squares <= 65,025, the two
-// red-mean weights <= 12,272), the green square and one v_dot2_u32_u16 — every intermediate exact.
+// first minimal key.  Per entry the table holds {r | b<<16, 8*(1024+r) | 8*(1534-r)<<16, g<<7, rgb8}; with the target's
+// {r | b<<16, 8r | (-8r)<<16, g<<7} one key is three packed 16-bit ops (differences, their squares <= 65,025, the two
+// red-mean weights <= 12,272), the green term 2048 * 8 * dg^2 = (dg<<7)^2 as one 24-bit multiply-add that also brings
+// the row's number (|dg<<7| < 2^15; the 32-bit v_mul_lo_u32 runs at a quarter of the rate) and one v_dot2_u32_u16 —
+// every intermediate exact.
 template <int N>
 __device__ __forceinline__ uint32_t dither_group_min(const uint4 *__restrict__ ent, uint32_t t1, uint32_t tw, int tg) {
     uint32_t k[8];
@@ -81,8 +83,8 @@ __device__ __forceinline__ uint32_t dither_group_min(const uint4 *__restrict__ e
             const u16x2 d = as_u16x2(e.x) - as_u16x2(t1);
             const u16x2 sq = d * d;
             const u16x2 wg = as_u16x2(e.y) + as_u16x2(tw);
-            const int dg = (int)e.z - tg;
-            k[u] = __builtin_amdgcn_udot2(sq, wg, ((uint32_t)(dg * dg) << 14) | (uint32_t)u, false);
+            const int dg = (int)e.z - tg; // (times 128)
+            k[u] = __builtin_amdgcn_udot2(sq, wg, (uint32_t)(__mul24(dg, dg) + u), false);
         } else k[u] = 0xffffffffu;
     }
     return min(min(min(k[0], k[1]), min(k[2], k[3])), min(min(k[4], k[5]), min(k[6], k[7])));
@@ -119,7 +121,7 @@ __device__ __forceinline__ void dither_body(const DitherParams &P, const int blk
         uint32_t c = P.pal_rgb8[i];
         if ((uint32_t)i == P.slot_ci) c = __float_as_uint(P.cand_tab[8 * (size_t)cand + 6]);
         const uint32_t r = c & 0xff, g = (c >> 8) & 0xff, b = (c >> 16) & 0xff;
-        s_ent[i] = make_uint4(r | (b << 16), (8u * (1024u + r)) | ((8u * (1534u - r)) << 16), g, c);
+        s_ent[i] = make_uint4(r | (b << 16), (8u * (1024u + r)) | ((8u * (1534u - r)) << 16), g << 7, c);
         if (PERC) {
             const float *src = ((uint32_t)i == P.slot_ci) ? P.cand_lab + 3 * (size_t)cand : P.pal_lab + 3 * (size_t)i;
             s_lab[3 * i] = src[0]; s_lab[3 * i + 1] = src[1]; s_lab[3 * i + 2] = src[2];
@@ -223,7 +225,7 @@ __device__ __forceinline__ void dither_body(const DitherParams &P, const int blk
                 const bool same = (rlo & 0x00ffffffu) == (tq[0] | (tq[1] << 8) | (tq[2] << 16));
                 if (!__any(!same)) { // every row of the wave is back on B's targets at its pixel: B's choice, or the candidate's colour where it beats B's key
                     const uint32_t t1 = tq[0] | (tq[2] << 16), tw = (8u * tq[0]) | ((0u - 8u * tq[0]) << 16);
-                    const uint32_t kc = dither_group_min<1>(s_ent + P.slot_ci, t1, tw, (int)tq[1]) >> 3;
+                    const uint32_t kc = dither_group_min<1>(s_ent + P.slot_ci, t1, tw, (int)(tq[1] << 7)) >> 3;
                     const int bb = (int)(rlo >> 24) - base; // (a transparent pixel's record holds ncol + 1: its index is not used)
                     best = (kc < rhi) ? (int)P.slot_ci - base : (opaque ? bb : 0); // rhi = 0 outside the slot's subpalette: never beaten
                     searched = true;
@@ -232,7 +234,7 @@ __device__ __forceinline__ void dither_body(const DitherParams &P, const int blk
             if (searched) {
             } else if (!PERC) {
                 const uint32_t t1 = tq[0] | (tq[2] << 16), tw = (8u * tq[0]) | ((0u - 8u * tq[0]) << 16);
-                const int tg = (int)tq[1];
+                const int tg = (int)(tq[1] << 7);
                 uint32_t bk = 0xffffffffu; int bbase = 0;
                 if (SUB) {
 #pragma unroll
@@ -333,7 +335,7 @@ __device__ __forceinline__ void dither4_body(const DitherParams &P, const int bl
         uint32_t col = P.pal_rgb8[i];
         if ((uint32_t)i == P.slot_ci) col = __float_as_uint(P.cand_tab[8 * (size_t)cand + 6]);
         const uint32_t r = col & 0xff, g = (col >> 8) & 0xff, b = (col >> 16) & 0xff;
-        s_ent[i] = make_uint4(r | (b << 16), (8u * (1024u + r)) | ((8u * (1534u - r)) << 16), g, col);
+        s_ent[i] = make_uint4(r | (b << 16), (8u * (1024u + r)) | ((8u * (1534u - r)) << 16), g << 7, col);
     }
     for (int i = tid; i < 1024; i += 512) s_tile[i] = P.tile_pal[i];
     if (q < 3) for (int s4 = 0; s4 < 4; s4++) ring[j][s4][q] = 0.0;
@@ -395,7 +397,7 @@ __device__ __forceinline__ void dither4_body(const DitherParams &P, const int bl
             const uint32_t tq0 = quad_bcast(tqc, 0), tq1 = quad_bcast(tqc, 1), tq2 = quad_bcast(tqc, 2);
             // the quad's lanes take entries q, q + 4, ...: 8 * key each (dither_group_min's arithmetic), first minimum kept
             const uint32_t t1 = tq0 | (tq2 << 16), tw = (8u * tq0) | ((0u - 8u * tq0) << 16);
-            const int tg = (int)tq1;
+            const int tg = (int)(tq1 << 7);
             uint32_t bk = 0xffffffffu, bi = 0xffu;
 #pragma unroll 4
             for (int i = 0; i < (SUB ? (SUB + 3) / 4 : 64); i++) {
@@ -405,8 +407,8 @@ __device__ __forceinline__ void dither4_body(const DitherParams &P, const int bl
                 const u16x2 d = as_u16x2(en.x) - as_u16x2(t1);
                 const u16x2 sq = d * d;
                 const u16x2 wg = as_u16x2(en.y) + as_u16x2(tw);
-                const int dg = (int)en.z - tg;
-                const uint32_t k8 = __builtin_amdgcn_udot2(sq, wg, (uint32_t)(dg * dg) << 14, false);
+                const int dg = (int)en.z - tg; // (times 128)
+                const uint32_t k8 = __builtin_amdgcn_udot2(sq, wg, (uint32_t)__mul24(dg, dg), false);
                 if (k8 < bk) { bk = k8; bi = (uint32_t)idx; }
             }
             { // lowest key, then lowest index, over the quad
@@ -490,7 +492,7 @@ __device__ __forceinline__ void ditherw_body(const DitherParams &P, const int bl
     for (int i = tid; i < P.ncol; i += 64 * RW) {
         const uint32_t c = P.pal_rgb8[(uint32_t)i == P.slot_ci ? slot_sub * sub_size + slot_j0 : i];
         const uint32_t r = c & 0xff, g = (c >> 8) & 0xff, b = (c >> 16) & 0xff;
-        s_ent[i] = make_uint4(r | (b << 16), (8u * (1024u + r)) | ((8u * (1534u - r)) << 16), g, c);
+        s_ent[i] = make_uint4(r | (b << 16), (8u * (1024u + r)) | ((8u * (1534u - r)) << 16), g << 7, c);
     }
     for (int i = tid; i < 1024; i += 64 * RW) s_tile[i] = P.tile_pal[i];
     __syncthreads(); // the only one: from here on the waves go their own ways
@@ -499,7 +501,7 @@ __device__ __forceinline__ void ditherw_body(const DitherParams &P, const int bl
     const int cand = P.order ? P.order[run] : run;
     uint4 own; // the run's colour, as a table entry
     { const uint32_t c = __float_as_uint(P.cand_tab[8 * (size_t)cand + 6]); const uint32_t r = c & 0xff, g = (c >> 8) & 0xff, b = (c >> 16) & 0xff;
-      own = make_uint4(r | (b << 16), (8u * (1024u + r)) | ((8u * (1534u - r)) << 16), g, c); }
+      own = make_uint4(r | (b << 16), (8u * (1024u + r)) | ((8u * (1534u - r)) << 16), g << 7, c); }
     const double w0 = 7.0 / 16.0, w1 = 3.0 / 16.0, w2 = 5.0 / 16.0, w3 = 1.0 / 16.0, mult = 0.8;
     uint8_t *map = P.maps + (size_t)cand * W * H;
     uint32_t *map4 = reinterpret_cast<uint32_t *>(map);
@@ -582,7 +584,7 @@ __device__ __forceinline__ void ditherw_body(const DitherParams &P, const int bl
                     tq[c] = (uint32_t)(tr + ((cl - tr >= 0.5) ? 1.0 : 0.0));
                 }
                 const uint32_t t1 = tq[0] | (tq[2] << 16), tw = (8u * tq[0]) | ((0u - 8u * tq[0]) << 16);
-                const int tg = (int)tq[1];
+                const int tg = (int)(tq[1] << 7);
                 const bool in_sub = base == slot_sub * sub_size;
                 int best = 0;        // the best entry other than the slot's
                 uint32_t thr = 0;    // the run's colour takes the pixel iff its key is below

@@ -222,16 +222,17 @@ __device__ __forceinline__ void sparse_scan_lab_body(const SparseParams &P) {
         // the few surviving lanes of every iteration.
         uint32_t *q = s_queue[w];
         int queued = 0; // wave-uniform
-        uint4 e_n = make_uint4(0, 0, 0, 0); float l_n = 0.0f; // entry and lightness of the wave's NEXT round, fetched a round ahead
-        if (64 * w + lane < n) { e_n = P.plist[64 * w + lane]; l_n = P.labpx[3 * (size_t)e_n.x]; }
+        uint4 e_n = make_uint4(0, 0, 0, 0); Lab t_n{0.0f, 0.0f, 0.0f}; // entry and colour of the wave's NEXT round, fetched a round ahead
+        if (64 * w + lane < n) { e_n = P.plist[64 * w + lane]; t_n.l = P.labpx[3 * (size_t)e_n.x]; t_n.a = P.labpx[3 * (size_t)e_n.x + 1]; t_n.b = P.labpx[3 * (size_t)e_n.x + 2]; }
+        const float cch = sqrtf(cl.a * cl.a + cl.b * cl.b);
         for (int i0 = 64 * w; i0 < n; i0 += 256) {
             const int i = i0 + lane;
-            const uint4 e = e_n; const float tl = l_n;
-            if (i + 256 < n) { e_n = P.plist[i + 256]; l_n = P.labpx[3 * (size_t)e_n.x]; }
+            const uint4 e = e_n; const Lab t = t_n;
+            if (i + 256 < n) { e_n = P.plist[i + 256]; t_n.l = P.labpx[3 * (size_t)e_n.x]; t_n.a = P.labpx[3 * (size_t)e_n.x + 1]; t_n.b = P.labpx[3 * (size_t)e_n.x + 2]; }
             bool maybe = false;
             if (i < n) {
                 if (e.z == 0xffffffffu) take(e.x);
-                else maybe = !(fabsf(cl.l - tl) > 1.752f * __uint_as_float(e.z & 0x7fffffffu)); // ciede2000_cannot_beat on the lightness alone
+                else { const float bd = __uint_as_float(e.z & 0x7fffffffu); maybe = !ciede2000_cannot_beat(cl, t, bd) && !ciede2000_cannot_beat_ab(cl, cch, t, bd); } // the two sure "no"s of color.hpp
             }
             const unsigned long long mm = __ballot(maybe);
             if (maybe) q[queued + __popcll(mm & ((1ull << lane) - 1ull))] = (uint32_t)i;
@@ -1021,6 +1022,7 @@ __global__ __launch_bounds__(256) void k_remap_won_lab(MapsParams P, const uint4
     Lab cl; cl.l = P.cand_lab[3 * cand]; cl.a = P.cand_lab[3 * cand + 1]; cl.b = P.cand_lab[3 * cand + 2];
     uint8_t *map = P.maps + (size_t)cand * P.npx;
     const int n = *plist_count;
+    const float cch = sqrtf(cl.a * cl.a + cl.b * cl.b);
     for (int i = lane; i < n; i += 64) {
         const uint4 e = plist[i];
         const uint32_t thr = e.z;
@@ -1028,7 +1030,7 @@ __global__ __launch_bounds__(256) void k_remap_won_lab(MapsParams P, const uint4
         if (!win) {
             Lab t; t.l = P.labpx[3 * (size_t)e.x]; t.a = P.labpx[3 * (size_t)e.x + 1]; t.b = P.labpx[3 * (size_t)e.x + 2];
             const float bd = __uint_as_float(thr & 0x7fffffffu);
-            if (!ciede2000_cannot_beat(cl, t, bd)) {
+            if (!ciede2000_cannot_beat(cl, t, bd) && !ciede2000_cannot_beat_ab(cl, cch, t, bd)) {
                 const float d = ciede2000(cl, t);
                 win = (d < bd) || ((thr & 0x80000000u) && d == bd); // strict <, ties to the lower index (lib.rs:788-791)
             }
