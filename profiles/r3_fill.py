@@ -16,7 +16,7 @@ for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(s
 shutil.copy(os.path.join(src, "shard_proxy.json"), "profiles/r3_shard_proxy.json")
 for f in glob.glob(os.path.join(src, "kernel_stats_*.txt")):
     shutil.copy(f, os.path.join("profiles", "r3_rocprofv3_" + os.path.basename(f)))
-for f in glob.glob(os.path.join(src, "timeline_*.txt")):
+for f in glob.glob(os.path.join(src, "timeline_*.txt")) + glob.glob(os.path.join(src, "steps_*.txt")) + glob.glob(os.path.join(src, "acceptance_*.txt")):
     shutil.copy(f, os.path.join("profiles", "r3_" + os.path.basename(f)))
 
 

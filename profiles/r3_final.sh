@@ -23,7 +23,10 @@ stats() { # name, script, args
 step "stats"
 stats rgb bench.py --no-cpu-baseline --no-extras || exit 1   # the default invocation's timed region (400 steps, 10 warm-up): the V pass's average must agree with roofline.avg_launch_ms
 stats perceptual bench.py --steps 25 --warmup 5 --no-cpu-baseline --no-extras --config perceptual || exit 1
-stats dither bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --config dither || exit 1
+TL=k_commit stats dither bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --config dither || exit 1   # (timeline: a call three from the end)
+bash profiles/r3_steps.sh r3final/steps_dither k_commit "k_dither4ILi15ELi1 k_ditherw k_sparse_v2E k_sparse_h2E k_sparse_down1 k_dither_diff" bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-extras --config dither > /dev/null || exit 1
+cp $O/steps_dither/steps.txt $O/steps_dither.txt
+python profiles/r3_acceptance.py > $O/acceptance_rgb.txt 2>/dev/null || exit 1
 stats images bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --config images || exit 1
 TL=kw_commit stats slots profiles/r3_slots.py --converge 100 --calls 960 --window 64 || exit 1
 TL=kw_commit stats slots_dither profiles/r3_slots.py --converge 100 --calls 480 --window 64 --config dither || exit 1

@@ -1106,7 +1106,7 @@ int32_t snesimage_remap_candidates_device(snesimage_ctx *c, uint32_t palette, ui
                     hipLaunchKernelGGL(k_build_plist, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, c->d_pack, (int)c->npx, c->d_rplist, c->d_rcount);
                 }
                 hipLaunchKernelGGL(k_remap_fill4, grid, dim3(256), 0, c->stream, M);
-                hipLaunchKernelGGL(k_remap_won_lab, dim3((nc + 3) / 4), dim3(256), 0, c->stream, M, (const uint4 *)c->d_rplist, (const int *)c->d_rcount);
+                hipLaunchKernelGGL(k_remap_won_lab, dim3(nc), dim3(256), 0, c->stream, M, (const uint4 *)c->d_rplist, (const int *)c->d_rcount);
             } else hipLaunchKernelGGL((k_remap4<false>), grid, dim3(256), 0, c->stream, M);
         }
     }

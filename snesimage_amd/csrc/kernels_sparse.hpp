@@ -1015,28 +1015,47 @@ __global__ __launch_bounds__(256) void k_remap_fill4(MapsParams P) {
     const int c0 = blockIdx.y * kRemapCands;
     for (int cc = 0; cc < kRemapCands && c0 + cc < P.ncand; cc++) reinterpret_cast<uint32_t *>(P.maps + (size_t)(c0 + cc) * P.npx)[q] = word;
 }
+// One block (four waves) per candidate, as in k_sparse_scan_lab: a lane that cannot rule its pixel out with the two sure
+// "no"s of color.hpp queues it, and the CIEDE2000 evaluation runs on full waves of queued pixels.
 __global__ __launch_bounds__(256) void k_remap_won_lab(MapsParams P, const uint4 *__restrict__ plist, const int *__restrict__ plist_count) {
-    const int lane = threadIdx.x & 63;
-    const int cand = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ uint32_t s_queue[4][128];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int cand = (int)blockIdx.x;
     if (cand >= P.ncand) return;
     Lab cl; cl.l = P.cand_lab[3 * cand]; cl.a = P.cand_lab[3 * cand + 1]; cl.b = P.cand_lab[3 * cand + 2];
+    const float cch = sqrtf(cl.a * cl.a + cl.b * cl.b);
     uint8_t *map = P.maps + (size_t)cand * P.npx;
     const int n = *plist_count;
-    const float cch = sqrtf(cl.a * cl.a + cl.b * cl.b);
-    for (int i = lane; i < n; i += 64) {
+    auto full_test = [&](int i) {
         const uint4 e = plist[i];
-        const uint32_t thr = e.z;
-        bool win = thr == 0xffffffffu;
-        if (!win) {
-            Lab t; t.l = P.labpx[3 * (size_t)e.x]; t.a = P.labpx[3 * (size_t)e.x + 1]; t.b = P.labpx[3 * (size_t)e.x + 2];
-            const float bd = __uint_as_float(thr & 0x7fffffffu);
-            if (!ciede2000_cannot_beat(cl, t, bd) && !ciede2000_cannot_beat_ab(cl, cch, t, bd)) {
-                const float d = ciede2000(cl, t);
-                win = (d < bd) || ((thr & 0x80000000u) && d == bd); // strict <, ties to the lower index (lib.rs:788-791)
+        Lab t; t.l = P.labpx[3 * (size_t)e.x]; t.a = P.labpx[3 * (size_t)e.x + 1]; t.b = P.labpx[3 * (size_t)e.x + 2];
+        const float d = ciede2000(cl, t), bd = __uint_as_float(e.z & 0x7fffffffu);
+        if ((d < bd) || ((e.z & 0x80000000u) && d == bd)) map[e.x] = (uint8_t)P.si; // strict <, ties to the lower index (lib.rs:788-791)
+    };
+    uint32_t *q = s_queue[w];
+    int queued = 0; // wave-uniform
+    for (int i0 = 64 * w; i0 < n; i0 += 256) {
+        const int i = i0 + lane;
+        bool maybe = false;
+        if (i < n) {
+            const uint4 e = plist[i];
+            if (e.z == 0xffffffffu) map[e.x] = (uint8_t)P.si;
+            else {
+                Lab t; t.l = P.labpx[3 * (size_t)e.x]; t.a = P.labpx[3 * (size_t)e.x + 1]; t.b = P.labpx[3 * (size_t)e.x + 2];
+                const float bd = __uint_as_float(e.z & 0x7fffffffu);
+                maybe = !ciede2000_cannot_beat(cl, t, bd) && !ciede2000_cannot_beat_ab(cl, cch, t, bd);
             }
         }
-        if (win) map[e.x] = (uint8_t)P.si;
+        const unsigned long long mm = __ballot(maybe);
+        if (maybe) q[queued + __popcll(mm & ((1ull << lane) - 1ull))] = (uint32_t)i;
+        queued += __popcll(mm);
+        if (queued >= 64) { // (the queue holds at most 127 entries)
+            full_test((int)q[lane]);
+            queued -= 64;
+            if (lane < queued) { const uint32_t v = q[64 + lane]; q[lane] = v; } // same-wave LDS traffic is ordered
+        }
     }
+    if (lane < queued) full_test((int)q[lane]);
 }
 
 // Longest first: the V pass of a candidate sweeps every column from its first changed group to the bottom, so blocks

@@ -172,6 +172,35 @@ def test_score_candidates_parity_with_maps(S, O, img256_alpha, flags, slot, n):
     g.close()
 
 
+def test_perceptual_remap_alone_equals_the_scoring_path_maps(S, O, img256_alpha):
+    """`snesimage_remap_candidates_device` with --perceptual-palettes: B's map for everyone, then CIEDE2000 win tests over the
+    slot's contested pixels only — pixels ruled out by the two sure "no"s of color.hpp (lightness; lightness and a-b plane),
+    the rest queued and evaluated on full waves.  Against the maps the scoring path hands out (every pixel searched over its
+    subpalette by the first-generation kernel) for 700 candidates, and against the oracle for a handful."""
+    from hipmem import DeviceArray
+    g, o = pair(S, O, img256_alpha, 8, 15, perceptual=True)
+    o.initialize_tiles()
+    o.recalculate_palettes()
+    sync_state(g, o)
+    n = 700
+    for slot in [(3, 5), (0, 0)]:
+        cand = S.random_candidates(11, slot[0] * 15 + slot[1], n)
+        cand[0] = o.palette[slot[0] * 15 + slot[1]]
+        cand[1] = o.palette[slot[0] * 15 + (slot[1] + 1) % 15]
+        d_c = DeviceArray.from_numpy(cand)
+        d_e = DeviceArray(n, np.float64, fill=0)
+        d_m = DeviceArray((n, 256, 256), np.uint8, fill=0)
+        d_r = DeviceArray((n, 256, 256), np.uint8, fill=7)
+        g.score_candidates_device(slot[0], slot[1], d_c.ptr, n, d_e.ptr, d_m.ptr)
+        g.remap_candidates_device(slot[0], slot[1], d_c.ptr, n, d_r.ptr)
+        g.sync()
+        a, b = d_m.numpy(), d_r.numpy()
+        assert np.array_equal(a, b), (slot, int(np.argmax((a != b).reshape(n, -1).any(axis=1))))
+        _, mo = o.score_candidates(slot[0], slot[1], cand[:4], want_maps=True)
+        assert np.array_equal(b[:4], mo)
+    g.close()
+
+
 def test_chunking_does_not_change_results(S, O, img256):
     g, o = pair(S, O, img256, 8, 15)
     o.initialize_tiles()
