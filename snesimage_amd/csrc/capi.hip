@@ -547,9 +547,10 @@ int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si) {
             sp.slot_ci = (uint32_t)(sp_idx * (int)c->sub_size + si);
             auto &ah = sp.ahead;
             const int *b_done = nullptr; // device flag: B's run for this slot and palette is in place already
-            if (ah.have && ah.sp == sp_idx && ah.si == si && ah.epoch + 1 == c->epoch && c->epoch_by_commit) {
+            const bool same_state = ah.epoch == c->epoch; // nothing has touched the palette since (a sweep of snesimage_score_candidates over the slots)
+            if (ah.have && ah.sp == sp_idx && ah.si == si && (same_state || (ah.epoch + 1 == c->epoch && c->epoch_by_commit))) {
                 std::swap(sp.bmap, ah.bmap); std::swap(sp.bmapC4, ah.bmapC4); std::swap(sp.dpack, ah.dpack); std::swap(sp.ckd, ah.ckd);
-                hipLaunchKernelGGL(k_ahead_ok, dim3(1), dim3(1), 0, c->stream, c->d_last, ah.ok); // the one commit since: did it keep the palette?
+                hipLaunchKernelGGL(k_ahead_ok, dim3(1), dim3(1), 0, c->stream, same_state ? (const StepResult *)nullptr : c->d_last, ah.ok); // the one commit since: did it keep the palette?
                 HIPCHK(hipStreamWaitEvent(c->stream, ah.ev, 0));
                 b_done = ah.ok;
             }

@@ -676,7 +676,7 @@ __global__ __launch_bounds__(1024) void k_keep_best(const double *__restrict__ e
     if (t == 0) { rec->err = be; rec->k = off + bi * stride; }
 }
 // sp.ahead (capi.hip): B's Floyd-Steinberg run for this call was made during the previous one; it stands iff that call's commit kept the palette
-__global__ void k_ahead_ok(const StepResult *__restrict__ last, int *__restrict__ ok) { *ok = last->changed ? 0 : 1; }
+__global__ void k_ahead_ok(const StepResult *__restrict__ last, int *__restrict__ ok) { *ok = (last && last->changed) ? 0 : 1; } // (last = nullptr: no commit in between)
 // After k_commit: if the winner was scored here, its map becomes the image's map and *skip = 1 (the re-dither is void);
 // likewise when nothing was accepted and the stored map already belongs to the palette.
 __global__ __launch_bounds__(1024) void k_take_best_map(const StepResult *__restrict__ last, const BestRec *__restrict__ recs, int nrec, const uint8_t *__restrict__ bestmaps, int npx,

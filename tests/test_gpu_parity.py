@@ -791,6 +791,9 @@ def test_dither_base_image_a_call_ahead(S, monkeypatch):
         assert e_p == e_a and np.array_equal(b_p, b_a), k
     assert np.array_equal(plain.palette, ahead.palette) and np.array_equal(plain.palette_map, ahead.palette_map)
     assert plain.error() == ahead.error()
+    for slot in [(2, 3), (2, 4), (2, 5), (2, 5), (6, 0)]:  # a sweep without commits: the B made ahead stands as it is
+        cand = S.random_candidates(3, slot[0] * 15 + slot[1], 80)
+        assert np.array_equal(plain.score_candidates(slot[0], slot[1], cand), ahead.score_candidates(slot[0], slot[1], cand)), slot
     plain.close()
     ahead.close()
 
