@@ -161,12 +161,13 @@ struct snesimage_ctx {
         // --dither (RGB distance): B dithered once per slot (k_dither MODE 1) and the candidates resumed from its checkpoints (MODE 2)
         uint8_t *dmaps = nullptr, *dmapsC4 = nullptr; // [lane][cap][W*H] candidates' palette_maps, row-major and C4
         uint8_t *bmap = nullptr, *bmapC4 = nullptr, *bcand = nullptr; unsigned long long *dpack = nullptr; double *ckd = nullptr; uint32_t slot_ci = 0;
+        float *rec_lab = nullptr; // --dither --perceptual-palettes: Lab of B's dithered targets (k_dither_first_lab)
         int base_sp = -1, base_si = -1; // slot B was built for (with --dither the pack does not depend on the slot, B does)
         // B's Floyd-Steinberg run a call ahead: while a call's candidates are scored, B of the scheduler's next slot (lib.rs:881-933
         // walks the slots in raster order) is dithered on B's stream into the second set of buffers, for the palette as it
         // stands.  The next call takes it if it is for that slot and the commit in between changed nothing (a flag on the
         // device: the host does not wait for the commit) — B's run then leaves at once — and dithers B itself otherwise.
-        struct Ahead { uint8_t *bmap = nullptr, *bmapC4 = nullptr, *bcand = nullptr; unsigned long long *dpack = nullptr; double *ckd = nullptr; float *btab = nullptr; int *ok = nullptr;
+        struct Ahead { uint8_t *bmap = nullptr, *bmapC4 = nullptr, *bcand = nullptr; unsigned long long *dpack = nullptr; double *ckd = nullptr; float *btab = nullptr, *blab = nullptr, *rec_lab = nullptr; int *ok = nullptr;
                        hipEvent_t ev = nullptr; bool on = true, have = false; int sp = -1, si = -1; unsigned long long epoch = 0; } ahead;
     } sp;
     // step state
@@ -496,12 +497,14 @@ int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
         HIPCHK(dmalloc(&sp.bmap, c->npx)); HIPCHK(dmalloc(&sp.bmapC4, c->npx)); HIPCHK(dmalloc(&sp.bcand, 64));
         HIPCHK(dmalloc(&sp.dpack, sizeof(unsigned long long) * c->npx));
         HIPCHK(dmalloc(&sp.ckd, sizeof(double) * 3 * c->W * (c->H / 4 + 1)));
+        dfree(sp.rec_lab); if (c->perceptual) HIPCHK(dmalloc(&sp.rec_lab, sizeof(float) * 3 * c->npx));
         auto &ah = sp.ahead;
-        dfree(ah.bmap); dfree(ah.bmapC4); dfree(ah.bcand); dfree(ah.dpack); dfree(ah.ckd); dfree(ah.btab); dfree(ah.ok); ah.have = false;
+        dfree(ah.bmap); dfree(ah.bmapC4); dfree(ah.bcand); dfree(ah.dpack); dfree(ah.ckd); dfree(ah.btab); dfree(ah.blab); dfree(ah.rec_lab); dfree(ah.ok); ah.have = false;
         if (ah.on && sp.side && c->sub_size > 1) {
             HIPCHK(dmalloc(&ah.bmap, c->npx)); HIPCHK(dmalloc(&ah.bmapC4, c->npx)); HIPCHK(dmalloc(&ah.bcand, 64)); HIPCHK(dmalloc(&ah.btab, sizeof(float) * 8)); HIPCHK(dmalloc(&ah.ok, sizeof(int)));
             HIPCHK(dmalloc(&ah.dpack, sizeof(unsigned long long) * c->npx));
             HIPCHK(dmalloc(&ah.ckd, sizeof(double) * 3 * c->W * (c->H / 4 + 1)));
+            if (c->perceptual) { HIPCHK(dmalloc(&ah.blab, sizeof(float) * 3)); HIPCHK(dmalloc(&ah.rec_lab, sizeof(float) * 3 * c->npx)); }
             if (!ah.ev) HIPCHK(hipEventCreateWithFlags(&ah.ev, hipEventDisableTiming));
         }
     }
@@ -525,6 +528,7 @@ SparseParams sparse_params(snesimage_ctx *c, uint32_t lane) {
     if (c->dither) {
         const uint32_t l = lane < c->nlanes ? lane : 0;
         P.use_maps = 1; P.sub_size = (int)c->sub_size; P.slot_ci = sp.slot_ci; P.subC4 = c->d_subC4; P.tile_pal = c->d_tile_pal;
+        P.perceptual = 0; P.labpx = sp.rec_lab; // (the scorer reads the runs' maps whatever distance made them; k_dither_first_lab: the targets' Lab)
         P.maps = sp.dmaps + (size_t)l * sp.cap * c->npx; P.mapsC4 = sp.dmapsC4 + (size_t)l * sp.cap * c->npx; P.bmap = sp.bmap; P.bmapC4 = sp.bmapC4;
     }
     return P;
@@ -549,7 +553,7 @@ int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si) {
             const int *b_done = nullptr; // device flag: B's run for this slot and palette is in place already
             const bool same_state = ah.epoch == c->epoch; // nothing has touched the palette since (a sweep of snesimage_score_candidates over the slots)
             if (ah.have && ah.sp == sp_idx && ah.si == si && (same_state || (ah.epoch + 1 == c->epoch && c->epoch_by_commit))) {
-                std::swap(sp.bmap, ah.bmap); std::swap(sp.bmapC4, ah.bmapC4); std::swap(sp.dpack, ah.dpack); std::swap(sp.ckd, ah.ckd);
+                std::swap(sp.bmap, ah.bmap); std::swap(sp.bmapC4, ah.bmapC4); std::swap(sp.dpack, ah.dpack); std::swap(sp.ckd, ah.ckd); std::swap(sp.rec_lab, ah.rec_lab);
                 hipLaunchKernelGGL(k_ahead_ok, dim3(1), dim3(1), 0, c->stream, same_state ? (const StepResult *)nullptr : c->d_last, ah.ok); // the one commit since: did it keep the palette?
                 HIPCHK(hipStreamWaitEvent(c->stream, ah.ev, 0));
                 b_done = ah.ok;
@@ -562,6 +566,12 @@ int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si) {
             Dp.orig = c->d_orig; Dp.tile_pal = c->d_tile_pal; Dp.pal_rgb8 = c->d_pal_rgb8; Dp.cand_tab = btab; Dp.maps = sp.bmap; Dp.mapsC4 = sp.bmapC4;
             Dp.W = (int)c->W; Dp.H = (int)c->H; Dp.sub_size = (int)c->sub_size; Dp.ncol = c->ncol; Dp.slot_ci = sp.slot_ci;
             Dp.rec_pack = sp.dpack; Dp.ck_out = sp.ckd; Dp.excl_sub = sp_idx; Dp.excl_si = si; Dp.excl_j0 = (int)j0; Dp.skip = b_done;
+            if (c->perceptual) { // CIEDE2000: the stand-in's Lab in B's row of the candidates' table, the record in distance bits, the targets' Lab beside it
+                float *blab = sp.cand_lab + 3 * (size_t)(c->nlanes * sp.cap);
+                hipLaunchKernelGGL(k_candidate_lab, dim3(1), dim3(64), 0, c->stream, btab, 1, c->d_lab_eotf, blab);
+                Dp.pal_lab = c->d_pal_lab; Dp.cand_lab = blab; Dp.lab_eotf = c->d_lab_eotf; Dp.perceptual = 1; Dp.rec_lab = sp.rec_lab;
+                hipLaunchKernelGGL((k_dither<true, 0, 1>), dim3(1), dim3(128), 0, c->stream, Dp);
+            } else
             if (c->dither4 && c->sub_size == 15) hipLaunchKernelGGL((k_dither4<15, 1>), dim3(1), dim3(512), 0, c->stream, Dp);
             else if (c->dither4) hipLaunchKernelGGL((k_dither4<0, 1>), dim3(1), dim3(512), 0, c->stream, Dp);
             else if (c->sub_size == 15) hipLaunchKernelGGL((k_dither<false, 15, 1>), dim3(1), dim3(128), 0, c->stream, Dp);
@@ -602,6 +612,11 @@ int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si) {
             Dn.orig = c->d_orig; Dn.tile_pal = c->d_tile_pal; Dn.pal_rgb8 = c->d_pal_rgb8; Dn.cand_tab = ah.btab; Dn.maps = ah.bmap; Dn.mapsC4 = ah.bmapC4;
             Dn.W = (int)c->W; Dn.H = (int)c->H; Dn.sub_size = (int)c->sub_size; Dn.ncol = c->ncol; Dn.slot_ci = (uint32_t)(np * (int)c->sub_size + ni);
             Dn.rec_pack = ah.dpack; Dn.ck_out = ah.ckd; Dn.excl_sub = np; Dn.excl_si = ni; Dn.excl_j0 = nj0;
+            if (c->perceptual) {
+                hipLaunchKernelGGL(k_candidate_lab, dim3(1), dim3(64), 0, bs, ah.btab, 1, c->d_lab_eotf, ah.blab);
+                Dn.pal_lab = c->d_pal_lab; Dn.cand_lab = ah.blab; Dn.lab_eotf = c->d_lab_eotf; Dn.perceptual = 1; Dn.rec_lab = ah.rec_lab;
+                hipLaunchKernelGGL((k_dither<true, 0, 1>), dim3(1), dim3(128), 0, bs, Dn);
+            } else
             if (c->dither4 && c->sub_size == 15) hipLaunchKernelGGL((k_dither4<15, 1>), dim3(1), dim3(512), 0, bs, Dn);
             else if (c->dither4) hipLaunchKernelGGL((k_dither4<0, 1>), dim3(1), dim3(512), 0, bs, Dn);
             else if (c->sub_size == 15) hipLaunchKernelGGL((k_dither<false, 15, 1>), dim3(1), dim3(128), 0, bs, Dn);
@@ -624,6 +639,10 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     if (c->timing) { for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&tr.ev[i])); HIPCHK(hipEventRecord(tr.ev[0], stream)); }
     hipLaunchKernelGGL(k_candidate_tables, dim3((nc + 63) / 64), dim3(64), 0, stream, d_rgb5, (int)nc, c->d_eotf, sp.cand_tab + 8 * (size_t)P.k0);
     if (c->dither) { // first pixel each candidate takes from B, then its own Floyd-Steinberg run from that 4-row group on
+        if (c->perceptual) {
+            hipLaunchKernelGGL(k_candidate_lab, dim3((nc + 63) / 64), dim3(64), 0, stream, sp.cand_tab + 8 * (size_t)P.k0, (int)nc, c->d_lab_eotf, sp.cand_lab + 3 * (size_t)P.k0);
+            hipLaunchKernelGGL(k_dither_first_lab, dim3(nc), dim3(256), 0, stream, P);
+        } else
         hipLaunchKernelGGL(k_dither_first, dim3((nc + 15) / 16), dim3(1024), 0, stream, P);
         DitherParams Dp{};
         Dp.orig = c->d_orig; Dp.tile_pal = c->d_tile_pal; Dp.pal_rgb8 = c->d_pal_rgb8; Dp.cand_tab = sp.cand_tab + 8 * (size_t)P.k0;
@@ -633,6 +652,10 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
         if (c->sp.lpt) { // the resumed runs differ several-fold in length: longest first (the order is rebuilt for the V pass below)
             hipLaunchKernelGGL(k_sparse_order, dim3(1), dim3(1024), 0, stream, P, sp.order + P.k0); Dp.order = sp.order + P.k0;
         }
+        if (c->perceptual) {
+            Dp.pal_lab = c->d_pal_lab; Dp.cand_lab = sp.cand_lab + 3 * (size_t)P.k0; Dp.lab_eotf = c->d_lab_eotf; Dp.perceptual = 1; Dp.rec_in = nullptr;
+            hipLaunchKernelGGL((k_dither<true, 0, 2>), dim3(nc), dim3(128), 0, stream, Dp);
+        } else
         if (c->dither4 && nc <= c->dither4_max && c->sub_size == 15) hipLaunchKernelGGL((k_dither4<15, 2>), dim3(nc), dim3(512), 0, stream, Dp);
         else if (c->dither4 && nc <= c->dither4_max) hipLaunchKernelGGL((k_dither4<0, 2>), dim3(nc), dim3(512), 0, stream, Dp);
         else if (c->ditherw && c->sub_size == 15) hipLaunchKernelGGL((k_ditherw<15>), dim3((nc + 3) / 4), dim3(256), 0, stream, Dp, (int)nc);
@@ -892,7 +915,7 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     if (const char *e = getenv("SNES_CHUNK")) { int v = atoi(e); if (v > 0) c->chunk = (uint32_t)v; }
     if (const char *e = getenv("SNES_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->nlanes = (uint32_t)v; }
     // the group-sparse path covers the no-dither remap (RGB keys or CIEDE2000) and the RGB Floyd-Steinberg remap
-    c->sp.enabled = (h >= 32) && !(c->dither && c->perceptual); // (B's downscale walks 32 x 32 blocks of pixels)
+    c->sp.enabled = (h >= 32); // (B's downscale walks 32 x 32 blocks of pixels)
     if (const char *e = getenv("SNES_SPARSE")) c->sp.enabled = c->sp.enabled && atoi(e) != 0;
     if (const char *e = getenv("SNES_BASE_STREAM")) c->sp.side = atoi(e) != 0;
     if (const char *e = getenv("SNES_LPT")) c->sp.lpt = atoi(e) != 0;
@@ -1003,7 +1026,7 @@ void snesimage_destroy(snesimage_ctx *c) {
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
     { auto &q = c->sp; if (q.base_stream) { (void)hipStreamSynchronize(q.base_stream); (void)hipStreamDestroy(q.base_stream); (void)hipEventDestroy(q.ev_base_in); (void)hipEventDestroy(q.ev_base_h); (void)hipEventDestroy(q.ev_base_narrow); (void)hipEventDestroy(q.ev_base_done); } dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.order); dfree(q.first); dfree(q.cand_lab); dfree(q.bitmap); dfree(q.ckh);
       dfree(q.dmaps); dfree(q.dmapsC4); dfree(q.bmap); dfree(q.bmapC4); dfree(q.bcand); dfree(q.dpack); dfree(q.ckd);
-      dfree(q.ahead.bmap); dfree(q.ahead.bmapC4); dfree(q.ahead.bcand); dfree(q.ahead.dpack); dfree(q.ahead.ckd); dfree(q.ahead.btab); dfree(q.ahead.ok); if (q.ahead.ev) (void)hipEventDestroy(q.ahead.ev); }
+      dfree(q.rec_lab); dfree(q.ahead.blab); dfree(q.ahead.rec_lab); dfree(q.ahead.bmap); dfree(q.ahead.bmapC4); dfree(q.ahead.bcand); dfree(q.ahead.dpack); dfree(q.ahead.ckd); dfree(q.ahead.btab); dfree(q.ahead.ok); if (q.ahead.ev) (void)hipEventDestroy(q.ahead.ev); }
     kmeans_free(c->km);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;

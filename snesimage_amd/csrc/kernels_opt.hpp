@@ -54,7 +54,9 @@ struct DitherParams {
     // MODE 1 (the base image B of a slot, dithered once with the slot's entry out of play) additionally leaves behind:
     unsigned long long *rec_pack; // per pixel, in the pack's format: lo = dithered target (8-bit, clamped and rounded as lib.rs:773-778) | B's colour index << 24,
                                   // hi = the key a candidate must beat to take the pixel (0 outside the slot's subpalette): the win test of k_dither_first
+                                  // (PERC: the bits of the CIEDE2000 distance to beat — non-negative binary32 values order as their bits — plus one where a tie goes to the slot)
     double *ck_out;               // [H/4 + 1][W][3]: diffused-error state entering row 4g (the v values of row 4g-1), g >= 1
+    float *rec_lab;               // PERC: the dithered target's Lab per pixel (what the search compared the entries with): k_dither_first_lab tests candidates against it
     int excl_sub, excl_si, excl_j0; // slot (subpalette, index); j0 = the other entry whose colour stands in for the slot's (see k_dither)
     // MODE 2 (a candidate resumed where it first differs from B):
     const int *first_group;       // per candidate: 4-row group holding its first won pixel in raster order (H/4 if it wins nothing); P.k0 offsets the index
@@ -266,6 +268,11 @@ __device__ __forceinline__ void dither_body(const DitherParams &P, const int blk
                     Lab el; el.l = s_lab[3 * (base + i)]; el.a = s_lab[3 * (base + i) + 1]; el.b = s_lab[3 * (base + i) + 2];
                     float d = ciede2000(el, tl);
                     if (i == 0 || d < bd) { bd = d; best = i; }
+                }
+                if (MODE == 1) {
+                    key_min = __float_as_uint(bd); // (a distance is never negative: its bits order as the values do, and bits + 1 is the next value up)
+                    float *rl = P.rec_lab + 3 * ((size_t)y * W + x);
+                    rl[0] = tl.l; rl[1] = tl.a; rl[2] = tl.b;
                 }
             }
             if (MODE == 1) { // B: the slot's entry is a stand-in for j0 (same colour, hence same key and same diffused error)

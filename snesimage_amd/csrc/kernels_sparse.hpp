@@ -346,6 +346,61 @@ __device__ __forceinline__ void dither_first_body(const SparseParams &P) {
     if (live && lane == 0) P.first[k] = first == 0x7fffffff ? (G.H >> 2) : (first / G.W) >> 2; // k_dither (MODE 2) resumes there
 }
 
+// The same with --perceptual-palettes: B's record holds the bits of the CIEDE2000 distance to beat (plus one where a tie goes
+// to the slot: see DitherParams::rec_pack) and the dithered targets' Lab values lie in P.labpx (B's run left them behind);
+// the candidate takes a pixel iff the bits of ciede2000(candidate, target) — the call the resumed run will make, argument
+// for argument — are below.  One block (four waves) per candidate, the two sure "no"s of color.hpp and full waves of
+// queued pixels as in k_sparse_scan_lab.
+__device__ __forceinline__ void dither_first_lab_body(const SparseParams &P) {
+    __shared__ uint32_t s_queue[4][128];
+    __shared__ int s_first;
+    const Geom &G = P.G;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wi = (int)blockIdx.x;
+    if (wi >= P.ncand) return;
+    const int k = P.k0 + wi;
+    if (threadIdx.x == 0) s_first = 0x7fffffff;
+    __syncthreads();
+    Lab cl; cl.l = P.cand_lab[3 * (size_t)k]; cl.a = P.cand_lab[3 * (size_t)k + 1]; cl.b = P.cand_lab[3 * (size_t)k + 2];
+    const float cch = sqrtf(cl.a * cl.a + cl.b * cl.b);
+    const int n = *P.plist_count;
+    int first = 0x7fffffff;
+    auto full_test = [&](int i) {
+        const uint4 e = P.plist[i];
+        Lab t; t.l = P.labpx[3 * (size_t)e.x]; t.a = P.labpx[3 * (size_t)e.x + 1]; t.b = P.labpx[3 * (size_t)e.x + 2];
+        if (__float_as_uint(ciede2000(cl, t)) < e.z) first = min(first, (int)e.x);
+    };
+    uint32_t *q = s_queue[w];
+    int queued = 0; // wave-uniform
+    for (int i0 = 64 * w; i0 < n; i0 += 256) {
+        const int i = i0 + lane;
+        bool maybe = false;
+        if (i < n) {
+            const uint4 e = P.plist[i];
+            if (e.z == 0xffffffffu) first = min(first, (int)e.x);
+            else {
+                Lab t; t.l = P.labpx[3 * (size_t)e.x]; t.a = P.labpx[3 * (size_t)e.x + 1]; t.b = P.labpx[3 * (size_t)e.x + 2];
+                const float bd = __uint_as_float(e.z); // the distance to beat, or the next value up
+                maybe = !ciede2000_cannot_beat(cl, t, bd) && !ciede2000_cannot_beat_ab(cl, cch, t, bd);
+            }
+        }
+        const unsigned long long mm = __ballot(maybe);
+        if (maybe) q[queued + __popcll(mm & ((1ull << lane) - 1ull))] = (uint32_t)i;
+        queued += __popcll(mm);
+        if (queued >= 64) {
+            full_test((int)q[lane]);
+            queued -= 64;
+            if (lane < queued) { const uint32_t v = q[64 + lane]; q[lane] = v; }
+        }
+    }
+    if (lane < queued) full_test((int)q[lane]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
+    if (lane == 0) atomicMin(&s_first, first);
+    __syncthreads();
+    if (threadIdx.x == 0) P.first[k] = s_first == 0x7fffffff ? (G.H >> 2) : (s_first / G.W) >> 2;
+}
+
 // ---- --dither: what did the resumed run change? -------------------------------------------------------------------
 // The error a changed pixel injects is diffused with a total weight of 0.8 per row, so it fades: away from the pixels the
 // candidate takes, its resumed run soon chooses what B chose.  The score depends on the picture only, so the changed set
@@ -1079,6 +1134,7 @@ __global__ __launch_bounds__(1024) void k_sparse_order(SparseParams P, int *__re
 __global__ __launch_bounds__(256) void k_sparse_scan_lab(SparseParams P) { sparse_scan_lab_body(P); }
 __global__ __launch_bounds__(1024) void k_sparse_scan(SparseParams P) { sparse_scan_body(P); }
 __global__ __launch_bounds__(1024) void k_dither_first(SparseParams P) { dither_first_body(P); }
+__global__ __launch_bounds__(256) void k_dither_first_lab(SparseParams P) { dither_first_lab_body(P); }
 __global__ __launch_bounds__(1024) void k_dither_diff(SparseParams P) { dither_diff_body(P); }
 __global__ __launch_bounds__(256) void k_sparse_down(SparseParams P, int only_scale) { sparse_down_body(P, only_scale, (int)blockIdx.x); }
 __global__ __launch_bounds__(256) void k_sparse_down1(SparseParams P) { sparse_down1_body(P, (int)blockIdx.x, (int)gridDim.x); }

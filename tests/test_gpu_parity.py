@@ -723,6 +723,48 @@ def test_resumed_dither_equals_full_dither(S, O, seed, variant, monkeypatch):
     sparse.close()
 
 
+def test_dither_with_perceptual_palettes_on_the_sparse_path(S, O, monkeypatch):
+    """--dither --perceptual-palettes through causality as well (round 3): B dithered with CIEDE2000 and the slot's entry out
+    of play, its record in distance bits (ties to the lower index as bits + 1) and the targets' Lab beside it; the first pixel
+    a candidate takes found by the very call the resumed run will make; resumed runs; group-sparse scoring of what differs.
+    Against the dense path (every candidate dithered from row 0, SNES_SPARSE=0) bit for bit — scores, committed colour,
+    committed map over consecutive slots (B a call ahead) — and against the oracle for a handful."""
+    from snesimage_amd.synth import synth_image
+    img = synth_image(0x5EED0003, variant=1)
+    monkeypatch.setenv("SNES_SPARSE", "0")
+    dense = S.OptimizedImage(img, 8, 15, dither=True, perceptual=True)
+    monkeypatch.delenv("SNES_SPARSE")
+    sparse = S.OptimizedImage(img, 8, 15, dither=True, perceptual=True)
+    dense.initialize_tiles()
+    dense.recalculate_palettes()
+    sparse.tile_palettes = dense.tile_palettes
+    sparse.palette = dense.palette
+    sparse.optimize()
+    pal = dense.palette
+    o = O.OracleImage(img, 8, 15, dither=True, perceptual=True)
+    o.tile_palettes = dense.tile_palettes
+    o.palette = dense.palette
+    o.optimize()
+    assert np.array_equal(sparse.palette_map, o.palette_map)
+    for slot in [(2, 3), (0, 0), (7, 14)]:
+        cand = S.random_candidates(21, slot[0] * 15 + slot[1], 96)
+        cand[0] = pal[slot[0] * 15 + slot[1]]
+        cand[1] = pal[slot[0] * 15 + (slot[1] + 1) % 15]   # the stand-in's colour: every tie with it goes by index
+        cand[2] = pal[slot[0] * 15 + (slot[1] + 14) % 15]
+        cand[3] = [0, 0, 0]
+        cand[4] = [31, 31, 31]
+        ed = dense.score_candidates(slot[0], slot[1], cand)
+        es = sparse.score_candidates(slot[0], slot[1], cand)
+        assert np.array_equal(ed, es), (slot, int(np.argmax(ed != es)), float(np.max(np.abs(ed - es))))
+        assert rel(es[:3], o.score_candidates(slot[0], slot[1], cand[:3])) < REL_ERR
+    for i, (p, idx) in enumerate([(3, 3), (3, 4), (3, 5), (3, 6), (0, 0)]):  # consecutive slots: B comes a call ahead
+        e_d, b_d = dense.step(S.METHOD_RANDOM, p, idx, 0, 9, i, 80)
+        e_s, b_s = sparse.step(S.METHOD_RANDOM, p, idx, 0, 9, i, 80)
+        assert e_d == e_s and np.array_equal(b_d, b_s) and np.array_equal(dense.palette_map, sparse.palette_map), i
+    dense.close()
+    sparse.close()
+
+
 @pytest.mark.parametrize("sub_count,sub_size", [(8, 15), (5, 7)])
 def test_long_dither_lists_one_wave_per_run(S, img256_alpha, sub_count, sub_size, monkeypatch):
     """Lists of more than 512 candidates resume their Floyd-Steinberg runs one wave per run (k_ditherw: the row above over
