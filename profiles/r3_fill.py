@@ -14,6 +14,8 @@ for c in ("rgb", "perceptual", "dither"):
 for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(src, "slots_*.json")):
     shutil.copy(f, os.path.join("profiles", "r3_" + os.path.basename(f)))
 shutil.copy(os.path.join(src, "shard_proxy.json"), "profiles/r3_shard_proxy.json")
+if os.path.exists(os.path.join(src, "dither_perceptual.json")):
+    shutil.copy(os.path.join(src, "dither_perceptual.json"), "profiles/r3_dither_perceptual.json")
 for f in glob.glob(os.path.join(src, "kernel_stats_*.txt")):
     shutil.copy(f, os.path.join("profiles", "r3_rocprofv3_" + os.path.basename(f)))
 for f in glob.glob(os.path.join(src, "timeline_*.txt")) + glob.glob(os.path.join(src, "steps_*.txt")) + glob.glob(os.path.join(src, "acceptance_*.txt")):

@@ -335,7 +335,8 @@ int32_t prep_for_slot(snesimage_ctx *c, int sp, int si) { return c->dither ? run
 
 // k_dither instantiations: the 15-colour subpalettes of the SNES 4bpp modes get a fully unrolled entry search
 void launch_dither(snesimage_ctx *c, const DitherParams &Dp, uint32_t nblocks) {
-    if (c->perceptual) hipLaunchKernelGGL((k_dither<true, 0>), dim3(nblocks), dim3(128), 0, c->stream, Dp);
+    if (c->perceptual && c->dither4 && nblocks <= c->dither4_max) hipLaunchKernelGGL((k_dither4_lab<0>), dim3(nblocks), dim3(512), 0, c->stream, Dp); // (optimize() of the committed palette: one run)
+    else if (c->perceptual) hipLaunchKernelGGL((k_dither<true, 0>), dim3(nblocks), dim3(128), 0, c->stream, Dp);
     else if (c->dither4 && nblocks <= c->dither4_max && c->sub_size == 15) hipLaunchKernelGGL((k_dither4<15, 0>), dim3(nblocks), dim3(512), 0, c->stream, Dp); // a quad of lanes per row: few runs
     else if (c->dither4 && nblocks <= c->dither4_max) hipLaunchKernelGGL((k_dither4<0, 0>), dim3(nblocks), dim3(512), 0, c->stream, Dp);
     else if (c->sub_size == 15) hipLaunchKernelGGL((k_dither<false, 15>), dim3(nblocks), dim3(128), 0, c->stream, Dp);
@@ -570,7 +571,7 @@ int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si) {
                 float *blab = sp.cand_lab + 3 * (size_t)(c->nlanes * sp.cap);
                 hipLaunchKernelGGL(k_candidate_lab, dim3(1), dim3(64), 0, c->stream, btab, 1, c->d_lab_eotf, blab);
                 Dp.pal_lab = c->d_pal_lab; Dp.cand_lab = blab; Dp.lab_eotf = c->d_lab_eotf; Dp.perceptual = 1; Dp.rec_lab = sp.rec_lab;
-                hipLaunchKernelGGL((k_dither<true, 0, 1>), dim3(1), dim3(128), 0, c->stream, Dp);
+                if (c->dither4) hipLaunchKernelGGL((k_dither4_lab<1>), dim3(1), dim3(512), 0, c->stream, Dp); else hipLaunchKernelGGL((k_dither<true, 0, 1>), dim3(1), dim3(128), 0, c->stream, Dp);
             } else
             if (c->dither4 && c->sub_size == 15) hipLaunchKernelGGL((k_dither4<15, 1>), dim3(1), dim3(512), 0, c->stream, Dp);
             else if (c->dither4) hipLaunchKernelGGL((k_dither4<0, 1>), dim3(1), dim3(512), 0, c->stream, Dp);
@@ -615,7 +616,7 @@ int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si) {
             if (c->perceptual) {
                 hipLaunchKernelGGL(k_candidate_lab, dim3(1), dim3(64), 0, bs, ah.btab, 1, c->d_lab_eotf, ah.blab);
                 Dn.pal_lab = c->d_pal_lab; Dn.cand_lab = ah.blab; Dn.lab_eotf = c->d_lab_eotf; Dn.perceptual = 1; Dn.rec_lab = ah.rec_lab;
-                hipLaunchKernelGGL((k_dither<true, 0, 1>), dim3(1), dim3(128), 0, bs, Dn);
+                if (c->dither4) hipLaunchKernelGGL((k_dither4_lab<1>), dim3(1), dim3(512), 0, bs, Dn); else hipLaunchKernelGGL((k_dither<true, 0, 1>), dim3(1), dim3(128), 0, bs, Dn);
             } else
             if (c->dither4 && c->sub_size == 15) hipLaunchKernelGGL((k_dither4<15, 1>), dim3(1), dim3(512), 0, bs, Dn);
             else if (c->dither4) hipLaunchKernelGGL((k_dither4<0, 1>), dim3(1), dim3(512), 0, bs, Dn);
@@ -654,7 +655,7 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
         }
         if (c->perceptual) {
             Dp.pal_lab = c->d_pal_lab; Dp.cand_lab = sp.cand_lab + 3 * (size_t)P.k0; Dp.lab_eotf = c->d_lab_eotf; Dp.perceptual = 1; Dp.rec_in = nullptr;
-            hipLaunchKernelGGL((k_dither<true, 0, 2>), dim3(nc), dim3(128), 0, stream, Dp);
+            if (c->dither4 && nc <= c->dither4_max) hipLaunchKernelGGL((k_dither4_lab<2>), dim3(nc), dim3(512), 0, stream, Dp); else hipLaunchKernelGGL((k_dither<true, 0, 2>), dim3(nc), dim3(128), 0, stream, Dp);
         } else
         if (c->dither4 && nc <= c->dither4_max && c->sub_size == 15) hipLaunchKernelGGL((k_dither4<15, 2>), dim3(nc), dim3(512), 0, stream, Dp);
         else if (c->dither4 && nc <= c->dither4_max) hipLaunchKernelGGL((k_dither4<0, 2>), dim3(nc), dim3(512), 0, stream, Dp);

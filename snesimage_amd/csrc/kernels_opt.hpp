@@ -325,10 +325,12 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v, int lane_in_quad) { /
          : lane_in_quad == 1 ? (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x55, 0xf, 0xf, false)
                              : (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xAA, 0xf, 0xf, false);
 }
-template <int SUB, int MODE>
+template <int SUB, int MODE, bool PERC = false>
 __device__ __forceinline__ void dither4_body(const DitherParams &P, const int blk) {
     constexpr int NT = 128; // rows in flight
     __shared__ uint4 s_ent[256];
+    __shared__ float s_lab[PERC ? 256 * 3 : 1]; // PERC: CIEDE2000 in Lab — the quad's lanes take entries q, q + 4, ... as below, ~2,000 instructions each
+    __shared__ float s_eotf[PERC ? 256 : 1];
     __shared__ double ring[NT][4][3];
     __shared__ uint8_t s_tile[1024];
     if (P.skip && *P.skip) return;
@@ -343,7 +345,12 @@ __device__ __forceinline__ void dither4_body(const DitherParams &P, const int bl
         if ((uint32_t)i == P.slot_ci) col = __float_as_uint(P.cand_tab[8 * (size_t)cand + 6]);
         const uint32_t r = col & 0xff, g = (col >> 8) & 0xff, b = (col >> 16) & 0xff;
         s_ent[i] = make_uint4(r | (b << 16), (8u * (1024u + r)) | ((8u * (1534u - r)) << 16), g << 7, col);
+        if (PERC) {
+            const float *src = ((uint32_t)i == P.slot_ci) ? P.cand_lab + 3 * (size_t)cand : P.pal_lab + 3 * (size_t)i;
+            s_lab[3 * i] = src[0]; s_lab[3 * i + 1] = src[1]; s_lab[3 * i + 2] = src[2];
+        }
     }
+    if (PERC) for (int i = tid; i < 256; i += 512) s_eotf[i] = P.lab_eotf[i];
     for (int i = tid; i < 1024; i += 512) s_tile[i] = P.tile_pal[i];
     if (q < 3) for (int s4 = 0; s4 < 4; s4++) ring[j][s4][q] = 0.0;
     __syncthreads();
@@ -406,6 +413,15 @@ __device__ __forceinline__ void dither4_body(const DitherParams &P, const int bl
             const uint32_t t1 = tq0 | (tq2 << 16), tw = (8u * tq0) | ((0u - 8u * tq0) << 16);
             const int tg = (int)(tq1 << 7);
             uint32_t bk = 0xffffffffu, bi = 0xffu;
+            Lab tl{0.0f, 0.0f, 0.0f};
+            if (PERC) { // the bits of a distance (never negative) order as the distances do: the quad's reduction below takes them as keys
+                tl = linear_to_lab(s_eotf[tq0], s_eotf[tq1], s_eotf[tq2]);
+                for (int idx = q; idx < sub_size; idx += 4) {
+                    Lab el; el.l = s_lab[3 * (base + idx)]; el.a = s_lab[3 * (base + idx) + 1]; el.b = s_lab[3 * (base + idx) + 2];
+                    const uint32_t kd = __float_as_uint(ciede2000(el, tl));
+                    if (kd < bk) { bk = kd; bi = (uint32_t)idx; }
+                }
+            } else
 #pragma unroll 4
             for (int i = 0; i < (SUB ? (SUB + 3) / 4 : 64); i++) {
                 const int idx = q + 4 * i;
@@ -425,10 +441,11 @@ __device__ __forceinline__ void dither4_body(const DitherParams &P, const int bl
                 if (pk < bk || (pk == bk && pi < bi)) { bk = pk; bi = pi; }
             }
             int best = (int)bi;
-            const uint32_t key_min = bk >> 3;
+            const uint32_t key_min = PERC ? bk : bk >> 3;
             if (MODE == 1) { // B: the slot's entry is a stand-in for j0 (same colour, hence same key and same diffused error)
                 const bool in_sub = base == P.excl_sub * sub_size;
                 if (in_sub && best == P.excl_si) best = P.excl_j0;
+                if (PERC && q == 0) { float *rl = P.rec_lab + 3 * ((size_t)y * W + x); rl[0] = tl.l; rl[1] = tl.a; rl[2] = tl.b; }
                 if (q == 0) {
                     const uint32_t thr = (in_sub && opaque) ? (sub_size == 1 ? 0xffffffffu : key_min + (P.excl_si < best ? 1u : 0u)) : 0u;
                     const uint32_t ci = opaque ? (uint32_t)(base + best) : (uint32_t)P.ncol + 1u;
@@ -1051,6 +1068,8 @@ template <bool PERC, int SUB, int MODE = 0, int NT = 128>
 __global__ __launch_bounds__(NT) void k_dither(DitherParams P) { dither_body<PERC, SUB, MODE, NT>(P, (int)blockIdx.x); }
 template <int SUB, int MODE>
 __global__ __launch_bounds__(512) void k_dither4(DitherParams P) { dither4_body<SUB, MODE>(P, (int)blockIdx.x); }
+template <int MODE>
+__global__ __launch_bounds__(512) void k_dither4_lab(DitherParams P) { dither4_body<0, MODE, true>(P, (int)blockIdx.x); }
 template <int SUB>
 __global__ __launch_bounds__(256) void k_ditherw(DitherParams P, int nrun) { ditherw_body<SUB>(P, (int)blockIdx.x, nrun); }
 __global__ void k_gen_candidates(int method, int n, unsigned long long key, const uint8_t *__restrict__ colors, int slot, int channel, uint8_t *__restrict__ cand,
