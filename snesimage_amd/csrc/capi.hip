@@ -654,7 +654,7 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
             hipLaunchKernelGGL(k_sparse_order, dim3(1), dim3(1024), 0, stream, P, sp.order + P.k0); Dp.order = sp.order + P.k0;
         }
         if (c->perceptual) {
-            Dp.pal_lab = c->d_pal_lab; Dp.cand_lab = sp.cand_lab + 3 * (size_t)P.k0; Dp.lab_eotf = c->d_lab_eotf; Dp.perceptual = 1; Dp.rec_in = nullptr;
+            Dp.pal_lab = c->d_pal_lab; Dp.cand_lab = sp.cand_lab + 3 * (size_t)P.k0; Dp.lab_eotf = c->d_lab_eotf; Dp.perceptual = 1;
             if (c->dither4 && nc <= c->dither4_max) hipLaunchKernelGGL((k_dither4_lab<2>), dim3(nc), dim3(512), 0, stream, Dp); else hipLaunchKernelGGL((k_dither<true, 0, 2>), dim3(nc), dim3(128), 0, stream, Dp);
         } else
         if (c->dither4 && nc <= c->dither4_max && c->sub_size == 15) hipLaunchKernelGGL((k_dither4<15, 2>), dim3(nc), dim3(512), 0, stream, Dp);

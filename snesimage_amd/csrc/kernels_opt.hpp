@@ -172,7 +172,7 @@ __device__ __forceinline__ void dither_body(const DitherParams &P, const int blk
     // perturbation a won pixel injects fades by 0.8 per row, so away from it the run's dithered target rounds to what B's
     // rounded to — and for the same rounded target the nearest-entry search over the fourteen other entries has B's result:
     // only the candidate's own colour has to be tested against the key B recorded (one key instead of fifteen, exact).
-    const bool use_rec = MODE == 2 && !PERC && P.rec_in != nullptr;
+    const bool use_rec = MODE == 2 && P.rec_in != nullptr;
     const uint4 *rec4 = reinterpret_cast<const uint4 *>(P.rec_in);
     uint4 ra_cur = make_uint4(0, 0, 0, 0), rb_cur = ra_cur, ra_nxt = ra_cur, rb_nxt = ra_cur;
     if (use_rec && y0 + j < H) { ra_nxt = rec4[(size_t)(y0 + j) * (W >> 1)]; rb_nxt = rec4[(size_t)(y0 + j) * (W >> 1) + 1]; }
@@ -226,8 +226,15 @@ __device__ __forceinline__ void dither_body(const DitherParams &P, const int blk
                 const uint32_t rhi = (x & 2) ? ((x & 1) ? rb_cur.w : rb_cur.y) : ((x & 1) ? ra_cur.w : ra_cur.y);
                 const bool same = (rlo & 0x00ffffffu) == (tq[0] | (tq[1] << 8) | (tq[2] << 16));
                 if (!__any(!same)) { // every row of the wave is back on B's targets at its pixel: B's choice, or the candidate's colour where it beats B's key
-                    const uint32_t t1 = tq[0] | (tq[2] << 16), tw = (8u * tq[0]) | ((0u - 8u * tq[0]) << 16);
-                    const uint32_t kc = dither_group_min<1>(s_ent + P.slot_ci, t1, tw, (int)(tq[1] << 7)) >> 3;
+                    uint32_t kc;
+                    if (PERC) { // (the record holds the bits of the distance to beat: one CIEDE2000 evaluation instead of sub_size)
+                        const Lab tl = linear_to_lab(s_eotf[tq[0]], s_eotf[tq[1]], s_eotf[tq[2]]);
+                        Lab el; el.l = s_lab[3 * P.slot_ci]; el.a = s_lab[3 * P.slot_ci + 1]; el.b = s_lab[3 * P.slot_ci + 2];
+                        kc = __float_as_uint(ciede2000(el, tl));
+                    } else {
+                        const uint32_t t1 = tq[0] | (tq[2] << 16), tw = (8u * tq[0]) | ((0u - 8u * tq[0]) << 16);
+                        kc = dither_group_min<1>(s_ent + P.slot_ci, t1, tw, (int)(tq[1] << 7)) >> 3;
+                    }
                     const int bb = (int)(rlo >> 24) - base; // (a transparent pixel's record holds ncol + 1: its index is not used)
                     best = (kc < rhi) ? (int)P.slot_ci - base : (opaque ? bb : 0); // rhi = 0 outside the slot's subpalette: never beaten
                     searched = true;
