@@ -91,7 +91,7 @@ def cpu_baseline(img, sub_count, sub_size, flags, tile_palettes, palette, budget
     one = make()
     cand = O.random_candidates(1, 123456, 4)
     t0 = time.perf_counter()
-    one.score_candidates(0, 0, cand)
+    e_cpu = one.score_candidates(0, 0, cand)
     per = (time.perf_counter() - t0) / 4
     single = 1.0 / per
     cores = min(os.cpu_count() or 1, 16)
@@ -103,7 +103,7 @@ def cpu_baseline(img, sub_count, sub_size, flags, tile_palettes, palette, budget
         list(ex.map(lambda a: a[0].score_candidates(0, 0, a[1]), zip(workers, lists)))
     dt = time.perf_counter() - t0
     return {"value": cores * per_thread / dt, "unit": "candidates/s", "cores": cores, "kind": "port",
-            "single_thread": single,
+            "single_thread": single, "_check": (cand, e_cpu, O.random_candidates(1, 654321, 60)),
             "sample": "%d candidates of slot (0,0) per thread on %d threads, full remap + full SSIMULACRA2 "
                       "with the source side recomputed per candidate (as lib.rs:506-525)" % (per_thread, cores)}
 
@@ -466,6 +466,18 @@ def main():
         out["remap_only"] = remap
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(img, sub_count, sub_size, flags, tile_palettes, palette)
+            # the four candidates the CPU leg scored first, at the head of a 64-candidate list on the measured (group-sparse) path:
+            # ties the figures above to results (north_star's bar: 1e-5 relative on the SSIMULACRA2 error)
+            cand4, e_cpu, rest = out["cpu_baseline"].pop("_check")
+            chk = S.OptimizedImage(img, sub_count, sub_size, dither=bool(flags & S.DITHER), perceptual=bool(flags & S.PERCEPTUAL), device=local_rank)
+            chk.tile_palettes, chk.palette = tile_palettes, palette
+            chk.optimize()
+            e_gpu = chk.score_candidates(0, 0, np.concatenate([cand4, rest]))[:4]
+            chk.close()
+            rel = float(np.max(np.abs(e_gpu - e_cpu) / np.abs(e_cpu)))
+            out["parity_check"] = {"candidates": 4, "list": 64, "max_rel_err": rel, "bar": 1e-5, "ok": bool(rel < 1e-5)}
+            if not rel < 1e-5:
+                raise SystemExit("bench.py: the measured path disagrees with the CPU oracle (max relative error %.3g): the measurement is void" % rel)
     image.close()
     if rank == 0:
         if world == 1 and args.config == "rgb" and not args.no_extras and not args.no_config_extras:
