@@ -554,7 +554,7 @@ __device__ __forceinline__ void ditherw_body(const DitherParams &P, const int bl
     const int passes = (nrows + 63) >> 6;
     const int nth = nrows < 64 ? nrows : 64;
     const int total_steps = 2 * (nth - 1) + passes * W;
-    double left[3] = {0.0, 0.0, 0.0}; // v(x-1, y) * 0.8; after the step, the value the lane above... below fetches
+    double left[3] = {0.0, 0.0, 0.0}; // v(x-1, y) * 0.8: this lane's left neighbour, and what lane j+1 fetches as its row above in the next step
     double u[3][3];                   // [age][channel]: the row above at columns x-1, x, x+1 (rotating: see the loop)
 #pragma unroll
     for (int a = 0; a < 3; a++) { u[a][0] = 0.0; u[a][1] = 0.0; u[a][2] = 0.0; }
