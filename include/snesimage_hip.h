@@ -105,7 +105,7 @@ int32_t snesimage_step_commit(snesimage_ctx *ctx, const double *d_errors);
  * (strict <, lib.rs:216-219), so a *window* scores the next K calls of the schedule against the current palette in one set
  * of launches, applies their decisions in order and stops behind the first call that changed the state; the calls behind
  * it are void and are scored again by the next window.  Bit-identical to snesimage_schedule_next + snesimage_step per
- * call, for every K.  Windows cover the group-sparse path (32 rows and more; not --dither together with --perceptual-palettes); other configurations are stepped call
+ * call, for every K.  Windows cover the group-sparse path (32 rows and more; with --dither, subpalettes of two entries and more); other configurations are stepped call
  * by call inside snesimage_run_slots. */
 typedef struct { double error; int32_t best_k; uint8_t rgb5[3]; uint8_t changed; } snesimage_call_result; /* what snesimage_last_step reports after the call */
 typedef struct {
@@ -163,8 +163,8 @@ int32_t snesimage_group_run_slots(snesimage_group *group, uint32_t n_calls, uint
 
 /* Throughput mode — many independent images on one device, one launch per stage of an optimizer call
  * for all of them (the reference runs one image per process: `run()` lib.rs:830-1024 once per file).
- * A batch borrows its contexts (same device, image size, palette geometry, chunk and flags — RGB redmean with or without
- * --dither, or --perceptual-palettes without): snesimage_batch_step_async is snesimage_step_async for every member — same slot and
+ * A batch borrows its contexts (same device, image size, palette geometry, chunk and flags — either distance, with or
+ * without --dither): snesimage_batch_step_async is snesimage_step_async for every member — same slot and
  * method, candidate stream of member i keyed (seeds[i], step_id), at most `chunk` candidates — enqueued
  * on the batch's stream.  Any other call on a member context first waits for that stream, and the first batched call
  * after such a call waits for the member's own stream; snesimage_set_chunk is refused on a lent context.  The batch does

@@ -43,6 +43,8 @@ python profiles/r3_slots.py --converge 100 --calls 1920 --window 1 > $O/slots_rg
 python profiles/r3_slots.py --converge 60 --calls 960 --config perceptual > $O/slots_perceptual_c60.json 2>/dev/null || exit 1
 python profiles/r3_slots.py --converge 60 --calls 960 --config dither > $O/slots_dither_c60.json 2>/dev/null || exit 1
 python profiles/r3_dither_perceptual.py 2048 16 > $O/dither_perceptual.json 2>/dev/null || exit 1
+python profiles/r3_slots.py --config dither_perceptual --converge 1 --calls 240 > $O/slots_dither_perceptual_c1.json 2>/dev/null || exit 1
+python profiles/r3_slots.py --config dither_perceptual --converge 1 --calls 120 --window 1 > $O/slots_dither_perceptual_c1_call_by_call.json 2>/dev/null || exit 1
 step "proxy"
 python profiles/shard_proxy.py --totals 64,4096,32768 --steps 40 --windows 64,128,256,480 > $O/shard_proxy.json 2> $O/shard_proxy.err || exit 1
 echo done

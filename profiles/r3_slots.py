@@ -2,7 +2,7 @@
 """Throughput of the reference's own optimizer loop (64 / 32 candidates per call, lib.rs:888-933) under speculative
 multi-slot stepping (snesimage_run_slots), on the BASELINE image: from the k-means start and from a converged palette.
 
-    python profiles/r3_slots.py [--config rgb|perceptual|dither] [--calls N] [--window W] [--converge SWEEPS]
+    python profiles/r3_slots.py [--config rgb|perceptual|dither|dither_perceptual] [--calls N] [--window W] [--converge SWEEPS]
 """
 import argparse
 import json
@@ -22,7 +22,7 @@ def main():
     args = ap.parse_args()
     import snesimage_amd as S
     from snesimage_amd.synth import synth_image
-    flags = {"rgb": {}, "perceptual": {"perceptual": True}, "dither": {"dither": True}}[args.config]
+    flags = {"rgb": {}, "perceptual": {"perceptual": True}, "dither": {"dither": True}, "dither_perceptual": {"dither": True, "perceptual": True}}[args.config]
     g = S.OptimizedImage(synth_image(), 8, 15, **flags)
     g.initialize_tiles()
     g.recalculate_palettes()

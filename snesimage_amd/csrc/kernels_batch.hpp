@@ -50,8 +50,13 @@ __global__ void kb_dither_prep(const BatchArgs *__restrict__ A, const int *__res
     SNES_BATCH_IMG;
     if ((int)threadIdx.x < a.nzero) a.zero[threadIdx.x] = 0;
     candidate_tables_body(a.bcolor, 1, a.eotf, a.btab);
+    if (a.Db.perceptual) candidate_lab_body(a.btab, 1, a.lab_eotf, const_cast<float *>(a.Db.cand_lab)); // (the same thread wrote the table's row)
 }
 template <int SUB> __global__ __launch_bounds__(512) void kb_dither_base(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; dither4_body<SUB, 1>(a.Db, 0); }
+__global__ __launch_bounds__(512) void kb_dither_base_lab(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; dither4_body<0, 1, true>(a.Db, 0); }
+__global__ __launch_bounds__(256) void kb_dither_first_lab(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; if ((int)blockIdx.x < a.n) dither_first_lab_body(a.Pc); }
+__global__ __launch_bounds__(512) void kb_dither_run4_lab(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; if ((int)blockIdx.x < a.n) dither4_body<0, 2, true>(a.Dc, (int)blockIdx.x); }
+__global__ __launch_bounds__(128) void kb_dither_run_lab(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; if ((int)blockIdx.x < a.n) dither_body<true, 0, 2>(a.Dc, (int)blockIdx.x); }
 __global__ __launch_bounds__(1024) void kb_dither_first(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; dither_first_body(a.Pc); }
 template <int SUB> __global__ __launch_bounds__(512) void kb_dither_run4(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; if ((int)blockIdx.x < a.n) dither4_body<SUB, 2>(a.Dc, (int)blockIdx.x); }
 template <int SUB> __global__ __launch_bounds__(128) void kb_dither_run(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; if ((int)blockIdx.x < a.n) dither_body<false, SUB, 2>(a.Dc, (int)blockIdx.x); }

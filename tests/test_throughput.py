@@ -17,7 +17,7 @@ def test_shard_images_is_a_partition(n, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("batched,flags", [(False, {}), (True, {}), (True, {"perceptual": True}), (True, {"dither": True})])
+@pytest.mark.parametrize("batched,flags", [(False, {}), (True, {}), (True, {"perceptual": True}), (True, {"dither": True}), (True, {"dither": True, "perceptual": True})])
 def test_concurrent_images_equal_one_at_a_time(batched, flags):
     """Optimizer calls of several images — enqueued side by side from several host threads, or issued as one launch per
     stage for all of them — give, for every image, exactly the state that stepping that image alone gives."""
@@ -47,14 +47,15 @@ def test_concurrent_images_equal_one_at_a_time(batched, flags):
 
 @pytest.mark.gpu
 def test_batch_rejects_what_it_does_not_cover():
+    """The batched launches cover the group-sparse path: images of 8 or 16 rows (dense path) are refused, not mis-stepped."""
     import snesimage_amd as S
-    from snesimage_amd.throughput import ImageBatch
-    for flags in ({"dither": True, "perceptual": True},):  # (CIEDE2000 inside Floyd-Steinberg stays on the dense path)
-        b = ImageBatch.synthetic([1, 2], 2, 3, candidates=8, batched=True, **flags)
-        with pytest.raises(S.SnesImageError) as e:
-            b.initialize()
-        assert e.value.code == -5
-        b.close()
+    from snesimage_amd.synth import synth_image
+    from snesimage_amd.throughput import IMAGE_SEED0, ImageBatch
+    b = ImageBatch(((i, synth_image(IMAGE_SEED0 + i, 256, 16)) for i in (1, 2)), 2, 3, candidates=8, batched=True)
+    with pytest.raises(S.SnesImageError) as e:
+        b.initialize()
+    assert e.value.code == -5
+    b.close()
 
 
 @pytest.mark.gpu
