@@ -735,11 +735,15 @@ def test_dither_with_perceptual_palettes_on_the_sparse_path(S, O, monkeypatch):
     dense = S.OptimizedImage(img, 8, 15, dither=True, perceptual=True)
     monkeypatch.delenv("SNES_SPARSE")
     sparse = S.OptimizedImage(img, 8, 15, dither=True, perceptual=True)
+    monkeypatch.setenv("SNES_DITHER4_MAX", "0")  # every list on the one-lane-per-row kernels (what lists of more than 512 take)
+    lanes = S.OptimizedImage(img, 8, 15, dither=True, perceptual=True)
+    monkeypatch.delenv("SNES_DITHER4_MAX")
     dense.initialize_tiles()
     dense.recalculate_palettes()
-    sparse.tile_palettes = dense.tile_palettes
-    sparse.palette = dense.palette
-    sparse.optimize()
+    for im in (sparse, lanes):
+        im.tile_palettes = dense.tile_palettes
+        im.palette = dense.palette
+        im.optimize()
     pal = dense.palette
     o = O.OracleImage(img, 8, 15, dither=True, perceptual=True)
     o.tile_palettes = dense.tile_palettes
@@ -756,6 +760,7 @@ def test_dither_with_perceptual_palettes_on_the_sparse_path(S, O, monkeypatch):
         ed = dense.score_candidates(slot[0], slot[1], cand)
         es = sparse.score_candidates(slot[0], slot[1], cand)
         assert np.array_equal(ed, es), (slot, int(np.argmax(ed != es)), float(np.max(np.abs(ed - es))))
+        assert np.array_equal(es, lanes.score_candidates(slot[0], slot[1], cand))
         assert rel(es[:3], o.score_candidates(slot[0], slot[1], cand[:3])) < REL_ERR
     for i, (p, idx) in enumerate([(3, 3), (3, 4), (3, 5), (3, 6), (0, 0)]):  # consecutive slots: B comes a call ahead
         e_d, b_d = dense.step(S.METHOD_RANDOM, p, idx, 0, 9, i, 80)
@@ -763,6 +768,7 @@ def test_dither_with_perceptual_palettes_on_the_sparse_path(S, O, monkeypatch):
         assert e_d == e_s and np.array_equal(b_d, b_s) and np.array_equal(dense.palette_map, sparse.palette_map), i
     dense.close()
     sparse.close()
+    lanes.close()
 
 
 @pytest.mark.parametrize("sub_count,sub_size", [(8, 15), (5, 7)])
