@@ -79,3 +79,22 @@ def test_product_never_touches_the_oracle():
     import subprocess
     out = subprocess.run(["ldd", os.path.join(pkg, "libsnesimage_hip.so")], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_library_in_the_tree_is_built_from_the_sources_in_the_tree():
+    """snesimage_version() carries the hash of the sources the library was built from (csrc/Makefile: SRC_HASH); bench.py
+    withholds counter figures stamped with another build's hash.  A library left behind by an earlier build — a header
+    comment edited, `make` not run — would void every committed counter summary at the next build: keep them in step."""
+    import glob
+    import hashlib
+    from snesimage_amd import _ffi
+    lib = _ffi.load()
+    v = lib.snesimage_version().decode()
+    assert "src:" in v
+    csrc = os.path.join(ROOT, "snesimage_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")) + glob.glob(os.path.join(csrc, "*.inc")), key=os.path.basename)
+    files += [os.path.join(ROOT, "include", "snesimage_hip.h"), os.path.join(ROOT, "include", "ssimulacra2_constants.h")]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(f, "rb").read())
+    assert v.split("src:")[1].strip() == h.hexdigest()[:16], "snesimage_amd/libsnesimage_hip.so is older than its sources: run make -C snesimage_amd/csrc"
