@@ -205,6 +205,9 @@ def main():
     ap.add_argument("--config", choices=["rgb", "perceptual", "dither", "images"], default="rgb")
     ap.add_argument("--chunk", type=int, default=0, help="candidates per launch group (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--job-timeout", type=float, default=1500.0,
+                    help="typed plainly with --gpus N > 1: seconds after which the launcher ends every rank and exits 124 (0 = none); "
+                         "a rank that dies ends the job at once either way (snesimage_amd/launch.py)")
     args = ap.parse_args()
     if not args.batch:
         args.batch = 64 if args.config == "images" else 4096
@@ -219,7 +222,7 @@ def main():
 
     from snesimage_amd.launch import needs_spawn, spawn_ranks
     if needs_spawn(args.gpus):  # typed as `python bench.py --gpus N`: this process becomes the launcher and never touches the GPU
-        code, out = spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:])
+        code, out = spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:], timeout=args.job_timeout or None)
         sys.stdout.write(out)
         sys.stdout.flush()
         raise SystemExit(code)
@@ -258,9 +261,13 @@ def main():
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
             else:
                 dist.init_process_group(backend, rank=rank, world_size=world)
-            warm = torch.zeros(1, device=device)
+            warm = torch.ones(1, device=device)
             dist.all_reduce(warm)
             torch.cuda.synchronize()
+            # one line per rank on stderr: what this rank sees, so that the record of a multi-GPU run shows the collective spanned N ranks
+            sys.stderr.write("bench rank %d/%d: device cuda:%d (%s) of %d visible, backend %s, dist world %d, warm-up all-reduce sum %g\n" % (
+                rank, world, local_rank, torch.cuda.get_device_name(local_rank), torch.cuda.device_count(), backend, dist.get_world_size(), float(warm.item())))
+            sys.stderr.flush()
         finally:
             sys.stdout.flush()
             os.dup2(saved, 1)
@@ -343,6 +350,31 @@ def main():
     tim = image.timing_read()
     image.timing_enable(False)
     err, best, _ = image.last_step()
+    # Beside the headline, never part of `value`: the channel sweeps of lib.rs:286-328 as the headline issues its random calls —
+    # call by call on the scheduler's slots, 32 candidates (the values of one channel) each, three calls per entry
+    channel_calls = None
+    if not args.no_extras:
+        kc = 360  # the channel sweep of one scheduler step at 8 x 15
+        base = n_slots + 5000
+
+        def run_ch(lo, hi):
+            for i in range(lo, hi):
+                e = (i // 3) % (sub_count * sub_size)
+                sharded_step(scorer, S.METHOD_CHANNEL, e // sub_size, e % sub_size, i % 3, seed, base + i, 32)
+        run_ch(0, 9)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0c = time.perf_counter()
+        run_ch(9, 9 + kc)
+        torch.cuda.synchronize()
+        dtc = time.perf_counter() - t0c
+        if world > 1:
+            t = torch.tensor([dtc], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtc = float(t.item())
+        channel_calls = {"calls": kc, "candidates_per_call": 32, "value": 32 * kc / dtc, "unit": "candidates/s", "ms_per_call": dtc / kc * 1e3,
+                         "note": "lib.rs:286-328 call by call (snesimage_step_begin / _commit), after the headline's timed region"}
 
     # Beside the headline (never part of `value`): the reference's own batch — 64 candidates per optimizer call (lib.rs:205),
     # sharded over the ranks like the headline — and, on several GPUs, the other scaling mode.
@@ -372,7 +404,7 @@ def main():
         ref_image.optimize()
         ref_scorer = HipWindowScorer(ref_image, device)
         ref_image.slots_reserve(64)
-        k64 = 840 if args.steps >= 100 else 120  # calls per leg: at 8 x 15, 840 calls are steps 0..4 of the schedule (480 random calls, 360 channel calls)
+        k64 = 840  # calls per leg whatever --steps: at 8 x 15, 840 calls are steps 0..4 of the schedule (480 random calls, 360 channel calls); ~0.04-0.2 s per leg
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -463,6 +495,8 @@ def main():
         if os.environ.get("SNES_BENCH_SHARE_GPU") == "1" or backend != "nccl":
             out["rehearsal"] = "ranks share one device / collective over %s: a rehearsal of the N > 1 code paths, not a measurement" % backend
         out.update(extras)
+        if channel_calls:
+            out["channel_calls"] = channel_calls
         out["remap_only"] = remap
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(img, sub_count, sub_size, flags, tile_palettes, palette)

@@ -1,5 +1,6 @@
 /* include/ssimulacra2_constants.h — every numeric constant of the restated third-party arithmetic behind `error()`
- * (lib.rs:503-548): ssimulacra2 0.5.1 (+ yuvxyb 0.4.2) as restated in SURVEY.md Appendix A.
+ * (lib.rs:503-548): ssimulacra2 0.5.1 (+ yuvxyb 0.4.2), and of palette 0.7.6's sRGB / XYZ / Lab conversions behind the
+ * CIEDE2000 distance and the k-means initialisers (lib.rs:101-103, 141-142, 1090-1100), as restated in SURVEY.md Appendix A.
  *
  * The reference pulls these from crates that are not vendored under /root/reference and cannot be fetched or built in this
  * environment, so the values below are a transcription from the published algorithm (libjxl tools/ssimulacra2.cc,
@@ -63,5 +64,69 @@
 #define SSIM2_SCORE_EXP 0.6276336467831387
 #define SSIM2_SCORE_GAIN (-10.0)
 #define SSIM2_SCORE_MAX 100.0
+
+/* ---- yuvxyb 0.4.2: sRGB transfer (TransferCharacteristic::SRGB) on binary32 values in [0,1] (lib.rs:518-525, 538-545) ----
+ * x < THRESHOLD ? x / LINEAR_DIV : ((x + OFFSET) / SCALE) ^ GAMMA.  (To the builder's recollection — unverifiable offline —
+ * upstream may port zimg's constants instead: SCALE 1.0550107, beta 0.0030412825, threshold 12.92 beta, and evaluate powf /
+ * cbrtf through yuvxyb-math's approximations; oracle_set_variant() measures what either would move: DESIGN.md section 2.) */
+#define SSIM2_SRGB_THRESHOLD 0.04045f
+#define SSIM2_SRGB_LINEAR_DIV 12.92f
+#define SSIM2_SRGB_OFFSET 0.055f
+#define SSIM2_SRGB_SCALE 1.055f
+#define SSIM2_SRGB_GAMMA 2.4f
+/* the zimg-style variant (oracle only, never the product): alpha, beta; linear below 12.92 beta, negative inputs clamp to 0 */
+#define SSIM2_ZIMG_SRGB_ALPHA 1.0550107f
+#define SSIM2_ZIMG_SRGB_BETA 0.0030412825f
+
+/* ---- palette 0.7.6: Srgb<u8> -> Lab<D65, f32> (lib.rs:101-103, 344-346, 1092-1097) and back (lib.rs:141-142, 369-371) ----
+ * Srgb::into_linear: x <= THRESHOLD ? x * (1 / 12.92) : (x * (1 / 1.055) + 0.055 / 1.055) ^ 2.4, constants formed in binary64 and
+ * rounded once (PALETTE_SRGB_*_D are the binary64 values the binary32 ones are rounded from) */
+#define PALETTE_SRGB_THRESHOLD 0.04045f
+#define PALETTE_SRGB_LINEAR_DIV_D 12.92
+#define PALETTE_SRGB_SCALE_D 1.055
+#define PALETTE_SRGB_OFFSET_D 0.055
+#define PALETTE_SRGB_GAMMA 2.4f
+#define PALETTE_SRGB_GAMMA_D 2.4
+#define PALETTE_SRGB_ENCODE_THRESHOLD_D 0.0031308
+/* linear sRGB -> XYZ (D65), rows X, Y, Z */
+#define PALETTE_XYZ_XR 0.4124564f
+#define PALETTE_XYZ_XG 0.3575761f
+#define PALETTE_XYZ_XB 0.1804375f
+#define PALETTE_XYZ_YR 0.2126729f
+#define PALETTE_XYZ_YG 0.7151522f
+#define PALETTE_XYZ_YB 0.0721750f
+#define PALETTE_XYZ_ZR 0.0193339f
+#define PALETTE_XYZ_ZG 0.1191920f
+#define PALETTE_XYZ_ZB 0.9503041f
+/* XYZ -> linear sRGB (binary64: the centres of the k-means initialisers are Lab<D65, f64>), rows R, G, B */
+#define PALETTE_RGB_RX 3.2404542
+#define PALETTE_RGB_RY (-1.5371385)
+#define PALETTE_RGB_RZ (-0.4985314)
+#define PALETTE_RGB_GX (-0.9692660)
+#define PALETTE_RGB_GY 1.8760108
+#define PALETTE_RGB_GZ 0.0415560
+#define PALETTE_RGB_BX 0.0556434
+#define PALETTE_RGB_BY (-0.2040259)
+#define PALETTE_RGB_BZ 1.0572252
+/* D65 white point */
+#define PALETTE_D65_X 0.95047f
+#define PALETTE_D65_Y 1.0f
+#define PALETTE_D65_Z 1.08883f
+#define PALETTE_D65_X_D 0.95047
+#define PALETTE_D65_Y_D 1.0
+#define PALETTE_D65_Z_D 1.08883
+/* Lab: f(t) = t > (6/29)^3 ? cbrt(t) : (841/108) t + 4/29; L = 116 f(y) - 16, a = 500 (f(x) - f(y)), b = 200 (f(y) - f(z)) */
+#define PALETTE_LAB_EPS_ROOT_D (6.0 / 29.0)
+#define PALETTE_LAB_KAPPA_D (841.0 / 108.0)
+#define PALETTE_LAB_KAPPA_INV_D (108.0 / 841.0)
+#define PALETTE_LAB_DELTA_D (4.0 / 29.0)
+#define PALETTE_LAB_L_SCALE 116.0f
+#define PALETTE_LAB_L_OFFSET 16.0f
+#define PALETTE_LAB_A_SCALE 500.0f
+#define PALETTE_LAB_B_SCALE 200.0f
+#define PALETTE_LAB_L_SCALE_D 116.0
+#define PALETTE_LAB_L_OFFSET_D 16.0
+#define PALETTE_LAB_A_SCALE_D 500.0
+#define PALETTE_LAB_B_SCALE_D 200.0
 
 #endif

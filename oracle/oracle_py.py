@@ -45,6 +45,7 @@ def lib():
         L.oracle_destroy.argtypes = [C.c_void_p]
         L.oracle_set_cache_source.argtypes = [C.c_void_p, C.c_int]
         L.oracle_set_blur_mode.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_set_variant.argtypes = [C.c_void_p, C.c_int]
         for name in ("oracle_initialize_tiles", "oracle_recalculate_palettes", "oracle_optimize"):
             getattr(L, name).argtypes = [C.c_void_p]
         L.oracle_error.argtypes = [C.c_void_p, _f64p]
@@ -260,6 +261,10 @@ class OracleImage:
 
     def set_blur_mode(self, mode):
         self._L.oracle_set_blur_mode(self._c, mode)
+
+    def set_variant(self, bits):
+        """What-if variants of the unpinned third-party arithmetic (snes_oracle.h: oracle_set_variant); 0 = the restatement."""
+        self._L.oracle_set_variant(self._c, bits)
 
     def set_cache_source(self, on):
         self._L.oracle_set_cache_source(self._c, int(on))

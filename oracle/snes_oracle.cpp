@@ -72,12 +72,12 @@ struct SrgbLut {
     SrgbLut() {
         for (int v = 0; v < 256; v++) {
             float x = (float)v / 255.0f; // into_format: u8 -> f32 stimulus
-            // Srgb::into_linear: x <= 0.04045 ? x/12.92 : ((x+0.055)/1.055)^2.4, f32; powf is
+            // Srgb::into_linear (constants: include/ssimulacra2_constants.h, PALETTE_SRGB_*), f32; powf is
             // evaluated through binary64 pow and rounded once (correctly rounded powf).
-            if (x <= 0.04045f) lin[v] = (float)(1.0 / 12.92) * x;
+            if (x <= PALETTE_SRGB_THRESHOLD) lin[v] = (float)(1.0 / PALETTE_SRGB_LINEAR_DIV_D) * x;
             else {
-                float t = fmaf(x, (float)(1.0 / 1.055), (float)(0.055 / 1.055));
-                lin[v] = (float)std::pow((double)t, (double)2.4f);
+                float t = fmaf(x, (float)(1.0 / PALETTE_SRGB_SCALE_D), (float)(PALETTE_SRGB_OFFSET_D / PALETTE_SRGB_SCALE_D));
+                lin[v] = (float)std::pow((double)t, (double)PALETTE_SRGB_GAMMA);
             }
         }
     }
@@ -87,22 +87,22 @@ const SrgbLut &srgb_lut() { static SrgbLut l; return l; }
 struct Lab32 { float l, a, b; };
 
 inline float lab_f(float c) {
-    const float epsilon = (float)(6.0 / 29.0) * (float)(6.0 / 29.0) * (float)(6.0 / 29.0); // powi(3)
-    const float kappa = (float)(841.0 / 108.0);
-    const float delta = (float)(4.0 / 29.0);
+    const float epsilon = (float)PALETTE_LAB_EPS_ROOT_D * (float)PALETTE_LAB_EPS_ROOT_D * (float)PALETTE_LAB_EPS_ROOT_D; // powi(3)
+    const float kappa = (float)PALETTE_LAB_KAPPA_D;
+    const float delta = (float)PALETTE_LAB_DELTA_D;
     return c > epsilon ? det_cbrtf(c) : (kappa * c) + delta;
 }
 inline Lab32 srgb8_to_lab(Rgb8 c) {
     const SrgbLut &L = srgb_lut();
     float r = L.lin[c.r], g = L.lin[c.g], b = L.lin[c.b];
     // sRGB -> XYZ (D65), Lindbloom's matrix as carried by palette's Srgb space.
-    float x = (r * 0.4124564f) + (g * 0.3575761f) + (b * 0.1804375f);
-    float y = (r * 0.2126729f) + (g * 0.7151522f) + (b * 0.0721750f);
-    float z = (r * 0.0193339f) + (g * 0.1191920f) + (b * 0.9503041f);
+    float x = (r * PALETTE_XYZ_XR) + (g * PALETTE_XYZ_XG) + (b * PALETTE_XYZ_XB);
+    float y = (r * PALETTE_XYZ_YR) + (g * PALETTE_XYZ_YG) + (b * PALETTE_XYZ_YB);
+    float z = (r * PALETTE_XYZ_ZR) + (g * PALETTE_XYZ_ZG) + (b * PALETTE_XYZ_ZB);
     // Xyz -> Lab: divide by the D65 white point, f(), then the affine map.
-    x = x / 0.95047f; y = y / 1.0f; z = z / 1.08883f;
+    x = x / PALETTE_D65_X; y = y / PALETTE_D65_Y; z = z / PALETTE_D65_Z;
     float fx = lab_f(x), fy = lab_f(y), fz = lab_f(z);
-    Lab32 o; o.l = (fy * 116.0f) - 16.0f; o.a = (fx - fy) * 500.0f; o.b = (fy - fz) * 200.0f;
+    Lab32 o; o.l = (fy * PALETTE_LAB_L_SCALE) - PALETTE_LAB_L_OFFSET; o.a = (fx - fy) * PALETTE_LAB_A_SCALE; o.b = (fy - fz) * PALETTE_LAB_B_SCALE;
     return o;
 }
 
@@ -169,17 +169,17 @@ inline double distance_cielab(Rgb8 c1, Rgb8 c2) { return (double)ciede2000(srgb8
 
 // palette 0.7.6: Lab<D65,f64> -> Xyz -> LinSrgb -> Srgb<f64> (clamped) -> Srgb<u8>  (lib.rs:141-142, 369-371)
 inline Rgb8 lab_to_srgb8(const double *lab) {
-    double y = (lab[0] + 16.0) / 116.0;
-    double x = y + (lab[1] / 500.0);
-    double z = y - (lab[2] / 200.0);
-    const double epsilon = 6.0 / 29.0, kappa = 108.0 / 841.0, delta = 4.0 / 29.0;
+    double y = (lab[0] + PALETTE_LAB_L_OFFSET_D) / PALETTE_LAB_L_SCALE_D;
+    double x = y + (lab[1] / PALETTE_LAB_A_SCALE_D);
+    double z = y - (lab[2] / PALETTE_LAB_B_SCALE_D);
+    const double epsilon = PALETTE_LAB_EPS_ROOT_D, kappa = PALETTE_LAB_KAPPA_INV_D, delta = PALETTE_LAB_DELTA_D;
     auto conv = [&](double c) { return c > epsilon ? c * c * c : (c - delta) * kappa; };
-    double X = conv(x) * 0.95047, Y = conv(y) * 1.0, Z = conv(z) * 1.08883;
-    double r = (X * 3.2404542) + (Y * -1.5371385) + (Z * -0.4985314);
-    double g = (X * -0.9692660) + (Y * 1.8760108) + (Z * 0.0415560);
-    double b = (X * 0.0556434) + (Y * -0.2040259) + (Z * 1.0572252);
+    double X = conv(x) * PALETTE_D65_X_D, Y = conv(y) * PALETTE_D65_Y_D, Z = conv(z) * PALETTE_D65_Z_D;
+    double r = (X * PALETTE_RGB_RX) + (Y * PALETTE_RGB_RY) + (Z * PALETTE_RGB_RZ);
+    double g = (X * PALETTE_RGB_GX) + (Y * PALETTE_RGB_GY) + (Z * PALETTE_RGB_GZ);
+    double b = (X * PALETTE_RGB_BX) + (Y * PALETTE_RGB_BY) + (Z * PALETTE_RGB_BZ);
     auto enc = [](double v) -> uint8_t {
-        double e = v <= 0.0031308 ? 12.92 * v : 1.055 * std::pow(v, 1.0 / 2.4) - 0.055;
+        double e = v <= PALETTE_SRGB_ENCODE_THRESHOLD_D ? PALETTE_SRGB_LINEAR_DIV_D * v : PALETTE_SRGB_SCALE_D * std::pow(v, 1.0 / PALETTE_SRGB_GAMMA_D) - PALETTE_SRGB_OFFSET_D;
         if (!(e >= 0.0)) e = 0.0; // clamp (NaN -> 0)
         if (e > 1.0) e = 1.0;
         return (uint8_t)std::nearbyint(e * 255.0); // from_format f64 -> u8: scale and round-to-nearest
@@ -414,25 +414,67 @@ void blur_fir(const float *in, float *out, int width, int height) {
             out[(size_t)y * width + x] = s;
         }
 }
+enum { MODE_FIR = 1, MODE_ZIMG_SRGB = 2, MODE_FAST_MATH = 4, MODE_PERTURB = 8 }; // bits of the oracle's `mode` (see the what-if variants below)
 void blur_plane(const float *in, float *out, int width, int height, int mode) {
-    if (mode == 1) { blur_fir(in, out, width, height); return; }
+    if (mode & MODE_FIR) { blur_fir(in, out, width, height); return; }
     std::vector<float> temp((size_t)width * height);
     for (int y = 0; y < height; y++) blur_horizontal_row(in + (size_t)y * width, temp.data() + (size_t)y * width, width);
     blur_vertical(temp.data(), out, width, height);
 }
 
+// ---- what-if variants of the unpinned third-party arithmetic (oracle only: DESIGN.md section 2, profiles/r4_exposure.py) ----
+// The `mode` integer that selects the blur (bit 0: the FIR stand-in of blur_fir) also carries, in its upper bits, variants
+// of yuvxyb's transfer function and of its powf / cbrtf, so that the distance between this restatement and what upstream
+// may compute can be MEASURED on the error() the optimizer sees.  Mode 0 is the restatement the product is held to.
+// MODE_FAST_MATH: powf and cbrtf evaluated in binary32 the way a fast-math crate would (yuvxyb-math is said to approximate
+// both): powf(x, y) = exp2f(y * log2f(x)) — the rounding of log2f is multiplied by y |log2 x|: ~1e-6 relative for x ~ 0.01 —
+// and cbrtf by a bit-hack seed with two Halley steps in binary32 (~2e-7 relative).
+inline float fast_powf(float x, float y) { return x > 0.0f ? exp2f(y * log2f(x)) : 0.0f; }
+inline float fast_cbrtf(float x) {
+    if (!(x > 0.0f)) return 0.0f;
+    uint32_t b; std::memcpy(&b, &x, 4);
+    b = b / 3u + 709958130u;
+    float t; std::memcpy(&t, &b, 4);
+    for (int i = 0; i < 2; i++) { const float t3 = t * t * t; t = t * ((t3 + 2.0f * x) / (2.0f * t3 + x)); }
+    return t;
+}
+// MODE_PERTURB: the exact result moved by a pseudo-random relative amount in [-1e-6, 1e-6] (a hash of its bits): "an
+// approximation good to 1e-6 whose error has no structure"
+inline float perturb_1e6(float v) {
+    uint32_t b; std::memcpy(&b, &v, 4);
+    uint64_t z = (uint64_t)b * 0x9E3779B97F4A7C15ull; z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
+    const double u = (double)(z & 0xfffffu) / 524287.5 - 1.0; // [-1, 1]
+    return (float)((double)v * (1.0 + 1e-6 * u));
+}
+inline float mode_powf(float x, float y, int mode) {
+    float r = (mode & MODE_FAST_MATH) ? fast_powf(x, y) : (float)std::pow((double)x, (double)y); // (exact: binary64 pow, rounded once)
+    return (mode & MODE_PERTURB) ? perturb_1e6(r) : r;
+}
+inline float mode_cbrtf(float x, int mode) {
+    float r = (mode & MODE_FAST_MATH) ? fast_cbrtf(x) : det_cbrtf(x);
+    return (mode & MODE_PERTURB) ? perturb_1e6(r) : r;
+}
+
 // yuvxyb 0.4.2: sRGB transfer (TransferCharacteristic::SRGB) on f32 in [0,1]; BT.709 primaries -> no-op.
+// Constants: include/ssimulacra2_constants.h (SSIM2_SRGB_*; MODE_ZIMG_SRGB: the zimg-style pair alpha / beta).
 struct EotfLut {
     float lin[256];
-    EotfLut() {
+    explicit EotfLut(int mode) {
         for (int v = 0; v < 256; v++) {
             float x = (float)v / 255.0f; // lib.rs:511-513, 531-533
-            if (x < 0.04045f) lin[v] = x / 12.92f;
-            else lin[v] = (float)std::pow((double)((x + 0.055f) / 1.055f), (double)2.4f);
+            if (mode & MODE_ZIMG_SRGB) {
+                x = x < 0.0f ? 0.0f : x;
+                if (x < SSIM2_SRGB_LINEAR_DIV * SSIM2_ZIMG_SRGB_BETA) lin[v] = x / SSIM2_SRGB_LINEAR_DIV;
+                else lin[v] = mode_powf((x + (SSIM2_ZIMG_SRGB_ALPHA - 1.0f)) / SSIM2_ZIMG_SRGB_ALPHA, SSIM2_SRGB_GAMMA, mode);
+            } else if (x < SSIM2_SRGB_THRESHOLD) lin[v] = x / SSIM2_SRGB_LINEAR_DIV;
+            else lin[v] = mode_powf((x + SSIM2_SRGB_OFFSET) / SSIM2_SRGB_SCALE, SSIM2_SRGB_GAMMA, mode);
         }
     }
 };
-const EotfLut &eotf_lut() { static EotfLut l; return l; }
+const EotfLut &eotf_lut(int mode) { // one table per variant (bits 1..3 of the mode)
+    static const EotfLut l[8] = {EotfLut(0), EotfLut(2), EotfLut(4), EotfLut(6), EotfLut(8), EotfLut(10), EotfLut(12), EotfLut(14)};
+    return l[(mode >> 1) & 7];
+}
 
 struct Img3 { int w = 0, h = 0; std::vector<float> p[3]; void resize(int W, int H) { w = W; h = H; for (auto &v : p) v.assign((size_t)W * H, 0.0f); } };
 
@@ -453,7 +495,7 @@ void downscale_by_2(const Img3 &in, Img3 &out) {
             }
 }
 // yuvxyb linear_rgb_to_xyb + ssimulacra2 make_positive_xyb, planar output
-inline void linear_rgb_to_positive_xyb(float r, float g, float b, float *X, float *Y, float *B) {
+inline void linear_rgb_to_positive_xyb(float r, float g, float b, float *X, float *Y, float *B, int mode = 0) {
     const float K_M02 = SSIM2_OPSIN_M02, K_M00 = SSIM2_OPSIN_M00, K_M01 = 1.0f - K_M02 - K_M00;
     const float K_M12 = SSIM2_OPSIN_M12, K_M10 = SSIM2_OPSIN_M10, K_M11 = 1.0f - K_M12 - K_M10;
     const float K_M20 = SSIM2_OPSIN_M20, K_M21 = SSIM2_OPSIN_M21, K_M22 = 1.0f - K_M20 - K_M21;
@@ -465,17 +507,18 @@ inline void linear_rgb_to_positive_xyb(float r, float g, float b, float *X, floa
     if (m0 < 0.0f) m0 = 0.0f;
     if (m1 < 0.0f) m1 = 0.0f;
     if (m2 < 0.0f) m2 = 0.0f;
-    m0 = det_cbrtf(m0) - K_B0_ROOT; m1 = det_cbrtf(m1) - K_B0_ROOT; m2 = det_cbrtf(m2) - K_B0_ROOT;
+    if (mode & (MODE_FAST_MATH | MODE_PERTURB)) { m0 = mode_cbrtf(m0, mode) - K_B0_ROOT; m1 = mode_cbrtf(m1, mode) - K_B0_ROOT; m2 = mode_cbrtf(m2, mode) - K_B0_ROOT; }
+    else { m0 = det_cbrtf(m0) - K_B0_ROOT; m1 = det_cbrtf(m1) - K_B0_ROOT; m2 = det_cbrtf(m2) - K_B0_ROOT; }
     float x = 0.5f * (m0 - m1), y = 0.5f * (m0 + m1), bb = m2;
     // make_positive_xyb
     *B = (bb - y) + SSIM2_POS_B_OFFSET;
     *X = fmaf(x, SSIM2_POS_X_SCALE, SSIM2_POS_X_OFFSET);
     *Y = y + SSIM2_POS_Y_OFFSET;
 }
-void to_positive_xyb(const Img3 &lin, Img3 &xyb) {
+void to_positive_xyb(const Img3 &lin, Img3 &xyb, int mode = 0) {
     xyb.resize(lin.w, lin.h);
     size_t n = (size_t)lin.w * lin.h;
-    for (size_t i = 0; i < n; i++) linear_rgb_to_positive_xyb(lin.p[0][i], lin.p[1][i], lin.p[2][i], &xyb.p[0][i], &xyb.p[1][i], &xyb.p[2][i]);
+    for (size_t i = 0; i < n; i++) linear_rgb_to_positive_xyb(lin.p[0][i], lin.p[1][i], lin.p[2][i], &xyb.p[0][i], &xyb.p[1][i], &xyb.p[2][i], mode);
 }
 
 const double SSIM2_WEIGHT[108] = SSIM2_WEIGHTS; // include/ssimulacra2_constants.h
@@ -496,7 +539,7 @@ void build_src_pyramid(const Img3 &lin0, int blur_mode, SrcPyramid &P) {
         if (width < 8 || height < 8) break;
         if (scale > 0) { Img3 d; downscale_by_2(lin, d); lin = d; width = lin.w; height = lin.h; }
         SrcScale S; S.w = width; S.h = height;
-        to_positive_xyb(lin, S.img1);
+        to_positive_xyb(lin, S.img1, blur_mode);
         S.mu1.resize(width, height); S.sigma1_sq.resize(width, height);
         mul.resize((size_t)width * height);
         for (int c = 0; c < 3; c++) {
@@ -577,7 +620,7 @@ double ssimulacra2_against(const SrcPyramid &P, const Img3 &dst_lin0, int blur_m
     for (size_t scale = 0; scale < P.scales.size(); scale++) {
         const SrcScale &S = P.scales[scale];
         if (scale > 0) { Img3 d; downscale_by_2(lin, d); lin = d; }
-        to_positive_xyb(lin, img2);
+        to_positive_xyb(lin, img2, blur_mode);
         int width = S.w, height = S.h;
         mu2.resize(width, height); s22.resize(width, height); s12.resize(width, height);
         mul.resize((size_t)width * height);
@@ -594,8 +637,8 @@ double ssimulacra2_against(const SrcPyramid &P, const Img3 &dst_lin0, int blur_m
     return msssim_score(stats);
 }
 
-void rgba_to_linear(const uint8_t *rgba, int w, int h, Img3 &out) {
-    const EotfLut &L = eotf_lut();
+void rgba_to_linear(const uint8_t *rgba, int w, int h, Img3 &out, int mode = 0) {
+    const EotfLut &L = eotf_lut(mode);
     out.resize(w, h);
     for (size_t i = 0; i < (size_t)w * h; i++) { out.p[0][i] = L.lin[rgba[4 * i]]; out.p[1][i] = L.lin[rgba[4 * i + 1]]; out.p[2][i] = L.lin[rgba[4 * i + 2]]; }
 }
@@ -688,11 +731,11 @@ double error_of(oracle_ctx *c) {
     std::vector<uint8_t> rgba((size_t)c->width * c->height * 4);
     as_rgba(c, rgba.data());
     if (!(c->cache_source && c->src_valid && c->src_mode == c->blur_mode)) {
-        Img3 src_lin; rgba_to_linear(c->original.data(), (int)c->width, (int)c->height, src_lin);
+        Img3 src_lin; rgba_to_linear(c->original.data(), (int)c->width, (int)c->height, src_lin, c->blur_mode);
         build_src_pyramid(src_lin, c->blur_mode, c->src);
         c->src_valid = true; c->src_mode = c->blur_mode;
     }
-    Img3 dst_lin; rgba_to_linear(rgba.data(), (int)c->width, (int)c->height, dst_lin);
+    Img3 dst_lin; rgba_to_linear(rgba.data(), (int)c->width, (int)c->height, dst_lin, c->blur_mode);
     return 100.0 - ssimulacra2_against(c->src, dst_lin, c->blur_mode);
 }
 
@@ -751,7 +794,8 @@ oracle_ctx *oracle_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t 
 }
 void oracle_destroy(oracle_ctx *c) { delete c; }
 void oracle_set_cache_source(oracle_ctx *c, int on) { c->cache_source = on; }
-void oracle_set_blur_mode(oracle_ctx *c, int mode) { c->blur_mode = mode; }
+void oracle_set_blur_mode(oracle_ctx *c, int mode) { c->blur_mode = (c->blur_mode & ~1) | (mode & 1); }
+void oracle_set_variant(oracle_ctx *c, int bits) { c->blur_mode = (c->blur_mode & 1) | ((bits & 7) << 1); }
 
 int oracle_optimize(oracle_ctx *c) { optimize(c); return 0; }
 
@@ -987,7 +1031,7 @@ int oracle_kmeans(const double *points, uint32_t n, uint32_t k, double *centres_
 
 int oracle_ssimulacra2_rgba(const uint8_t *src, const uint8_t *dst, uint32_t w, uint32_t h, int blur_mode, double *score) {
     if (w < 8 || h < 8) return fail("image smaller than 8x8");
-    Img3 a, b; rgba_to_linear(src, (int)w, (int)h, a); rgba_to_linear(dst, (int)w, (int)h, b);
+    Img3 a, b; rgba_to_linear(src, (int)w, (int)h, a, blur_mode); rgba_to_linear(dst, (int)w, (int)h, b, blur_mode);
     SrcPyramid P; build_src_pyramid(a, blur_mode, P);
     *score = ssimulacra2_against(P, b, blur_mode);
     return 0;

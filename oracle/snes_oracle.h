@@ -34,6 +34,11 @@ void oracle_set_cache_source(oracle_ctx *, int on);
 /* 0 (default): recursive-Gaussian blur exactly as restated from ssimulacra2 0.5.1.
  * 1: mathematically equivalent zero-padded 9-tap FIR (an experiment knob for tests only). */
 void oracle_set_blur_mode(oracle_ctx *, int mode);
+/* What-if variants of the UNPINNED third-party arithmetic behind error() (never the product's arithmetic):
+ * bit 0: zimg-style sRGB transfer constants in yuvxyb's EOTF (alpha 1.0550107, beta 0.0030412825, linear below 12.92 beta),
+ * bit 1: powf / cbrtf evaluated in binary32 as a fast-math crate would (exp2f(y log2f(x)); bit-hack seed + two Halley steps),
+ * bit 2: the exact powf / cbrtf results moved by a pseudo-random relative amount of at most 1e-6.  0 (default): the restatement. */
+void oracle_set_variant(oracle_ctx *, int bits);
 
 int oracle_initialize_tiles(oracle_ctx *);       /* lib.rs:79-189  */
 int oracle_recalculate_palettes(oracle_ctx *);   /* lib.rs:407-415 */

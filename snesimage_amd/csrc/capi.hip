@@ -75,9 +75,9 @@ BlurK make_blur_constants() {
 void make_eotf_tables(float *ssim_eotf, float *lab_eotf) {
     for (int v = 0; v < 256; v++) {
         const float x = (float)v / 255.0f;
-        ssim_eotf[v] = x < 0.04045f ? x / 12.92f : (float)std::pow((double)((x + 0.055f) / 1.055f), (double)2.4f);
-        lab_eotf[v] = x <= 0.04045f ? (float)(1.0 / 12.92) * x
-                                    : (float)std::pow((double)std::fmaf(x, (float)(1.0 / 1.055), (float)(0.055 / 1.055)), (double)2.4f);
+        ssim_eotf[v] = x < SSIM2_SRGB_THRESHOLD ? x / SSIM2_SRGB_LINEAR_DIV : (float)std::pow((double)((x + SSIM2_SRGB_OFFSET) / SSIM2_SRGB_SCALE), (double)SSIM2_SRGB_GAMMA); // include/ssimulacra2_constants.h
+        lab_eotf[v] = x <= PALETTE_SRGB_THRESHOLD ? (float)(1.0 / PALETTE_SRGB_LINEAR_DIV_D) * x
+                                                  : (float)std::pow((double)std::fmaf(x, (float)(1.0 / PALETTE_SRGB_SCALE_D), (float)(PALETTE_SRGB_OFFSET_D / PALETTE_SRGB_SCALE_D)), (double)PALETTE_SRGB_GAMMA);
     }
 }
 

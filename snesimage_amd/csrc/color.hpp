@@ -58,19 +58,19 @@ constexpr uint32_t kNesColorCount = 56;
 struct Lab { float l, a, b; };
 
 SNES_HD float lab_f(float c) {
-    const float epsilon = (float)(6.0 / 29.0) * (float)(6.0 / 29.0) * (float)(6.0 / 29.0);
-    const float kappa = (float)(841.0 / 108.0);
-    const float delta = (float)(4.0 / 29.0);
+    const float epsilon = (float)PALETTE_LAB_EPS_ROOT_D * (float)PALETTE_LAB_EPS_ROOT_D * (float)PALETTE_LAB_EPS_ROOT_D; // include/ssimulacra2_constants.h
+    const float kappa = (float)PALETTE_LAB_KAPPA_D;
+    const float delta = (float)PALETTE_LAB_DELTA_D;
     return c > epsilon ? d_cbrtf(c) : (kappa * c) + delta;
 }
 // lin_* : linear-light components from the 256-entry sRGB table (built on the host, see capi)
 SNES_HD Lab linear_to_lab(float r, float g, float b) {
-    float x = (r * 0.4124564f) + (g * 0.3575761f) + (b * 0.1804375f);
-    float y = (r * 0.2126729f) + (g * 0.7151522f) + (b * 0.0721750f);
-    float z = (r * 0.0193339f) + (g * 0.1191920f) + (b * 0.9503041f);
-    x = x / 0.95047f; y = y / 1.0f; z = z / 1.08883f;
+    float x = (r * PALETTE_XYZ_XR) + (g * PALETTE_XYZ_XG) + (b * PALETTE_XYZ_XB);
+    float y = (r * PALETTE_XYZ_YR) + (g * PALETTE_XYZ_YG) + (b * PALETTE_XYZ_YB);
+    float z = (r * PALETTE_XYZ_ZR) + (g * PALETTE_XYZ_ZG) + (b * PALETTE_XYZ_ZB);
+    x = x / PALETTE_D65_X; y = y / PALETTE_D65_Y; z = z / PALETTE_D65_Z;
     float fx = lab_f(x), fy = lab_f(y), fz = lab_f(z);
-    Lab o; o.l = (fy * 116.0f) - 16.0f; o.a = (fx - fy) * 500.0f; o.b = (fy - fz) * 200.0f;
+    Lab o; o.l = (fy * PALETTE_LAB_L_SCALE) - PALETTE_LAB_L_OFFSET; o.a = (fx - fy) * PALETTE_LAB_A_SCALE; o.b = (fy - fz) * PALETTE_LAB_B_SCALE;
     return o;
 }
 

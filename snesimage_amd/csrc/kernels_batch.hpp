@@ -160,6 +160,7 @@ __global__ __launch_bounds__(1024) void kw_commit(const WindowSlot *__restrict__
             StepResult r; r.error = inc; r.best_k = -1; r.rgb5[0] = colors[3 * slot]; r.rgb5[1] = colors[3 * slot + 1]; r.rgb5[2] = colors[3 * slot + 2]; r.changed = 0;
             log[j] = r;
         }
+        __syncthreads(); // the records above read `colors`; the accepting call's decision below rewrites its slot (an earlier call of the window may be on the same slot)
         if (threadIdx.x != 0) return;
         consumed = first;
         if (first < K) {

@@ -26,11 +26,17 @@ def free_port():
     return port
 
 
-def spawn_ranks(n_ranks, argv, env_extra=None, timeout=None):
+def spawn_ranks(n_ranks, argv, env_extra=None, timeout=None, poll_s=0.05):
     """Run `python argv...` as n_ranks ranks (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as
-    torch.distributed.run sets them).  Returns (worst exit code, rank 0's stdout)."""
+    torch.distributed.run sets them).  Returns (exit code, rank 0's stdout).
+
+    Every rank is watched, not rank 0 alone: a rank that dies leaves its peers waiting in the rendezvous or in a collective
+    for ever, so the first rank that exits non-zero ends the job — the others are terminated by pid, one line on stderr says
+    which rank failed with what, and its code is the job's.  `timeout` (seconds, None = unlimited) bounds the whole job: 124."""
+    import tempfile
+    import time
     port = free_port()
-    procs = []
+    procs, out0 = [], tempfile.TemporaryFile()  # rank 0's stdout goes to a file: nobody has to drain a pipe while the ranks are watched
     for r in range(n_ranks):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n_ranks), "LOCAL_WORLD_SIZE": str(n_ranks),
@@ -38,18 +44,42 @@ def spawn_ranks(n_ranks, argv, env_extra=None, timeout=None):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs across processes on these hosts
         if env_extra:
             env.update(env_extra)
-        procs.append(subprocess.Popen([sys.executable, *argv], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, code = b"", 0
+        procs.append(subprocess.Popen([sys.executable, *argv], env=env, stdout=out0 if r == 0 else subprocess.DEVNULL))
+    code, t0 = 0, time.monotonic()
     try:
-        out, _ = procs[0].communicate(timeout=timeout)
-        for p in procs:
-            rc = p.wait(timeout=timeout)
-            code = rc if abs(rc) > abs(code) else code
-    except subprocess.TimeoutExpired:
-        code = 124
+        live = set(range(n_ranks))
+        while live:
+            for r in sorted(live):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                live.discard(r)
+                if rc != 0 and code == 0:
+                    code = rc
+                    if live:
+                        sys.stderr.write("launch: rank %d of %d exited with code %d; terminating ranks %s\n" % (r, n_ranks, rc, sorted(live)))
+                        sys.stderr.flush()
+            if code != 0:
+                break
+            if timeout is not None and time.monotonic() - t0 > timeout:
+                sys.stderr.write("launch: job still running after %.0f s; terminating ranks %s\n" % (timeout, sorted(live)))
+                sys.stderr.flush()
+                code = 124
+                break
+            if live:
+                time.sleep(poll_s)
     finally:
         for p in procs:  # a rank that outlives the job (a failed peer left it waiting) is ended by its own pid, never by pattern
             if p.poll() is None:
-                p.kill()
-                p.wait()
+                p.terminate()
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+    out0.seek(0)
+    out = out0.read()
+    out0.close()
     return code, out.decode()

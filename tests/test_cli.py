@@ -200,6 +200,13 @@ def test_cli_devices_flag_gives_the_single_device_result(tmp_path):
     r2 = run(args[0], str(b), *args[1:], "--devices", "0")
     assert r1.returncode == 0 and r2.returncode == 0, r2.stdout + r2.stderr
     assert "launch sets" in r2.stdout and a.read_text() == b.read_text()
+    # the group starts from the state recalculate_palettes leaves (a palette_map that is not optimize() of the palette): only
+    # the first call is stepped alone, the rest go through windows — fewer launch sets than calls, as in the plain run
+    import re
+    m1, m2 = re.search(r"Ran (\d+) calls in (\d+) launch sets", r1.stdout), re.search(r"Ran (\d+) calls in (\d+) launch sets", r2.stdout)
+    assert m1 and m2 and int(m2.group(1)) == 40
+    assert int(m2.group(2)) < 40, "--devices fell back to one launch set per call: %s" % m2.group(0)
+    assert int(m1.group(2)) < 40
 
 
 def _log_lines(stdout):

@@ -46,6 +46,32 @@ def test_spawn_ranks_runs_one_process_per_rank_and_relays_rank0(tmp_path):
     assert code == 3  # a failing rank fails the job
 
 
+def test_a_rank_that_dies_before_the_rendezvous_ends_the_job(tmp_path, capfd):
+    """Rank 1 exits before init_process_group: rank 0 would wait in the rendezvous for ever.  The launcher watches every
+    rank, names the one that failed on stderr, ends the others by pid and returns the failing rank's code — promptly."""
+    import time
+    from snesimage_amd.launch import spawn_ranks
+    child = tmp_path / "child.py"
+    child.write_text("import os, sys\nif os.environ['RANK'] == '1':\n    sys.exit(7)\n" + CHILD)
+    t0 = time.monotonic()
+    code, out = spawn_ranks(2, [str(child)], timeout=600)
+    dt = time.monotonic() - t0
+    assert code == 7
+    assert dt < 120, "the job must end when the rank dies, not at the rendezvous' own timeout (took %.0f s)" % dt
+    assert not [l for l in out.splitlines() if l.startswith("{")]  # rank 0 never got through the rendezvous
+    err = capfd.readouterr().err
+    assert "rank 1 of 2 exited with code 7" in err
+
+
+def test_job_timeout_ends_every_rank(tmp_path, capfd):
+    from snesimage_amd.launch import spawn_ranks
+    child = tmp_path / "child.py"
+    child.write_text("import time\ntime.sleep(600)\n")
+    code, _ = spawn_ranks(2, [str(child)], timeout=2)
+    assert code == 124
+    assert "still running" in capfd.readouterr().err
+
+
 def test_bench_spawns_before_touching_the_gpu():
     """bench.py consults the launcher before it imports torch or the library (a process that has initialised HIP must not
     be turned into ranks)."""

@@ -152,11 +152,46 @@ def test_ssim2_constants_live_in_one_header():
     vals = [float(t) for t in w.replace("\n", " ").split(",") if t.strip()]
     assert len(vals) == 108 and abs(sum(vals) - 888.3148365876134) < 1e-9  # checksum of the transcription
     a = open(os.path.join(root, "oracle", "snes_oracle.cpp")).read()
-    b = "".join(open(os.path.join(root, "snesimage_amd", "csrc", f)).read() for f in ("kernels.hpp", "color.hpp", "capi.hip"))
+    b = "".join(open(os.path.join(root, "snesimage_amd", "csrc", f)).read() for f in ("kernels.hpp", "color.hpp", "capi.hip", "kmeans_host.inc"))
     for text in (a, b):
         assert "ssimulacra2_constants.h" in text and "SSIM2_WEIGHTS" in text
         for literal in ("0.9562382616834844", "0.0037930732552754493", "225.20515300849274", "0.24342268924547819", "3.2795"):
             assert literal not in text, literal
+        # round 4: yuvxyb's sRGB transfer and palette's sRGB / XYZ / Lab constants as well (they were literals on both sides)
+        for literal in ("0.04045", "12.92", "1.055", "0.4124564", "0.7151522", "0.95047", "1.08883", "3.2404542", "0.0031308", "841.0", "6.0 / 29.0"):
+            assert literal not in text, literal
+        assert "SSIM2_SRGB_THRESHOLD" in text and "PALETTE_XYZ_XR" in text and "PALETTE_D65_X" in text
+    for name in ("SSIM2_SRGB_THRESHOLD 0.04045f", "SSIM2_SRGB_LINEAR_DIV 12.92f", "SSIM2_SRGB_SCALE 1.055f", "SSIM2_SRGB_GAMMA 2.4f", "PALETTE_XYZ_YG 0.7151522f",
+                 "PALETTE_D65_Z 1.08883f", "PALETTE_RGB_RX 3.2404542"):
+        assert "#define " + name in hdr, name
+
+
+def test_unpinned_exposure_of_error_is_measured(O, img256):
+    """Row (c) of the scope table: the third-party arithmetic behind error() is unpinned.  The oracle's what-if variants
+    (oracle_set_variant: zimg-style sRGB constants, fast-math powf / cbrtf, 1e-6 perturbed powf / cbrtf) bound what a
+    difference between this restatement and upstream would do to the error the optimizer sees.  The table in DESIGN.md section 2
+    comes from profiles/r4_exposure.py (committed: profiles/r4_unpinned_exposure.json); here: the variants are real, small,
+    leave variant 0 untouched, and the committed table says what this run says."""
+    o = O.OracleImage(img256, 8, 15, cache_source=True)
+    o.initialize_tiles()
+    o.recalculate_palettes()
+    cand = O.random_candidates(1, 1000, 6)
+    e0, c0 = o.error(), o.score_candidates(0, 3, cand)
+    seen = {}
+    for bits in (1, 2, 4):
+        o.set_variant(bits)
+        e, c = o.error(), o.score_candidates(0, 3, cand)
+        rel = max(abs(e - e0) / e0, float(np.max(np.abs(c - c0) / c0)))
+        assert 0.0 < rel < 1e-3, (bits, rel)  # a real change of the arithmetic, and a small one
+        seen[bits] = abs(e - e0) / e0
+    o.set_variant(0)
+    assert o.error() == e0 and np.array_equal(o.score_candidates(0, 3, cand), c0)  # the restatement itself is untouched
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = json.load(open(os.path.join(root, "profiles", "r4_unpinned_exposure.json")))
+    assert [r["variant"] for r in doc["rows"]] == [1, 2, 3, 4] and abs(doc["incumbent_error"] - e0) < 1e-9 * e0
+    for r in doc["rows"]:
+        if r["variant"] in seen:
+            assert abs(r["incumbent_error_rel_change"] - seen[r["variant"]]) < 1e-9
 
 
 # ---- KAT 7: JSON shape (lib.rs:579-625) ------------------------------------------------------------
