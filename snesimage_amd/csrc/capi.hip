@@ -139,7 +139,6 @@ struct snesimage_ctx {
     // takes the winner's map instead of dithering the image again (lib.rs:237 re-runs optimize() on the winner's palette)
     uint8_t *d_bestmap = nullptr, *d_bestmaps_all = nullptr; BestRec *d_bestrec = nullptr, *d_bestrecs_all = nullptr; int *d_skip = nullptr;
     uint4 *d_rplist = nullptr; int *d_rcount = nullptr; // contested pixels for the perceptual remap-only entry point
-    bool dbg_stale_base = false; // SNES_DEBUG_STALE_BASE=1: the pack and the base image B of the FIRST slot stand in for every later slot's — results are WRONG; timing only: what a call costs with B's whole phase off its critical path (profiles/shard_proxy.py)
     bool map_pending = false; // without dither the optimize() that ends a step (lib.rs:237) is deferred until something reads palette_map
     bool best_valid = false, map_synced = false; // records belong to the list being committed; d_map is optimize() of the current palette
     // Additional launch lanes: chunk i of a candidate list runs on lane i % nlanes (lane 0 = the context's stream and the
@@ -153,7 +152,6 @@ struct snesimage_ctx {
         bool counters_cleared = false; // k_prep cleared B's counters for the current pack
         uint32_t h2q_max = 512; // longest list that takes k_sparse_h2q (SNES_H2Q_MAX; 0 = never)
         uint32_t hgrid = 8192; // most blocks per scale of k_sparse_h (grid-stride beyond)
-        bool dbg_have_base = false;
         bool enabled = false, side = true; uint32_t min_n = 64; uint32_t cap = 0; // cap = candidates per lane the arrays were sized for
         SparseGeom S{};
         float *store = nullptr, *cand_tab = nullptr, *cand_lab = nullptr, *ckf = nullptr, *ckh = nullptr; long long zeros_off = 0; uint32_t *bitmap = nullptr; double *cka = nullptr, *part = nullptr;
@@ -313,7 +311,6 @@ int32_t ensure_source(snesimage_ctx *c) {
 
 int32_t run_prep(snesimage_ctx *c, int mode, int sp, int si) {
     if (c->pack_valid && c->pack_mode == mode && (mode != 2 || (c->pack_sp == sp && c->pack_si == si))) return SNES_OK;
-    if (c->dbg_stale_base && mode == 2 && c->pack_mode == 2 && c->sp.plist_count) { c->pack_valid = true; c->pack_sp = sp; c->pack_si = si; return SNES_OK; } // TIMING EXPERIMENT ONLY (wrong results): see dbg_stale_base
     CHECK(ensure_tables(c));
     if (c->perceptual) CHECK(ensure_source(c));
     PrepParams P{};
@@ -471,7 +468,7 @@ int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
     }
     HIPCHK(dmalloc(&sp.ckf, sizeof(float) * (size_t)okf));
     // B's H-pass checkpoints, then 12 W floats of zeros (what the V pass prefetches for the group below the image)
-    dfree(sp.ckh); HIPCHK(dmalloc(&sp.ckh, sizeof(float) * (size_t)(okh + 12LL * G.W)));
+    dfree(sp.ckh); HIPCHK(dmalloc(&sp.ckh, sizeof(float) * (size_t)(okh + 12LL * G.W + 256))); // (+ 256 floats of scratch: SparseParams::trash)
     sp.zeros_off = okh;
     HIPCHK(hipMemsetAsync(sp.ckh + okh, 0, sizeof(float) * 12 * (size_t)G.W, c->stream));
     HIPCHK(dmalloc(&sp.cka, sizeof(double) * (size_t)oka));
@@ -527,7 +524,7 @@ SparseParams sparse_params(snesimage_ctx *c, uint32_t lane) {
     P.img1C4 = c->d_img1C4; P.mu1R4 = c->d_mu1R4; P.sd1R4 = c->d_sd1R4; P.a1R4 = c->d_a1R4; P.r1R4 = c->d_r1R4;
     P.store = sp.store; P.meta = sp.meta;
     P.items = sp.items + (size_t)lane * sp.item_stride * kItemLists; P.item_count = sp.item_count + (size_t)lane * kItemLists; P.item_stride = sp.item_stride; // lane == nlanes: B
-    P.ckf = sp.ckf; P.cka = sp.cka; P.part = sp.part; P.first = sp.first; P.ckh = sp.ckh; P.zeros = sp.ckh + sp.zeros_off;
+    P.ckf = sp.ckf; P.cka = sp.cka; P.part = sp.part; P.first = sp.first; P.ckh = sp.ckh; P.zeros = sp.ckh + sp.zeros_off; P.trash = sp.ckh + sp.zeros_off + 12LL * c->G.W;
     for (P.s_first = 0; P.s_first < c->G.nscales && c->G.sw[P.s_first] >= 64; P.s_first++) {} // first narrow scale
     if (c->dither) {
         const uint32_t l = lane < c->nlanes ? lane : 0;
@@ -544,9 +541,7 @@ static size_t h2_lds(const snesimage_ctx *c) { return sizeof(float) * 3 * (size_
 int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si) {
     auto &sp = c->sp;
     const Geom &G = c->G;
-    if (c->dbg_stale_base && sp.dbg_have_base) return SNES_OK; // TIMING EXPERIMENT ONLY (wrong results)
     if (!sp.plist_valid) {
-        sp.dbg_have_base = true;
         if (!sp.counters_cleared) HIPCHK(hipMemsetAsync(sp.item_count + (size_t)c->nlanes * kItemLists, 0, sizeof(int) * (kItemLists + 1), c->stream)); // normally k_prep did it
         sp.counters_cleared = false; // about to be used
         const unsigned long long *win_pack = c->d_pack;
@@ -933,7 +928,6 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     if (const char *e = getenv("SNES_DITHER4_MAX")) { int v = atoi(e); if (v >= 0) c->dither4_max = (uint32_t)v; }
     if (const char *e = getenv("SNES_H2Q_MAX")) { int v = atoi(e); if (v >= 0) c->sp.h2q_max = (uint32_t)v; }
     if (const char *e = getenv("SNES_HGRID")) { int v = atoi(e); if (v >= 1) c->sp.hgrid = (uint32_t)v; }
-    if (const char *e = getenv("SNES_DEBUG_STALE_BASE")) c->dbg_stale_base = atoi(e) != 0;
     if (const char *e = getenv("SNES_SPARSE_MIN")) { int v = atoi(e); if (v >= 1) c->sp.min_n = (uint32_t)v; }
     Geom &G = c->G;
     G.W = (int)w; G.H = (int)h; G.nscales = 0;

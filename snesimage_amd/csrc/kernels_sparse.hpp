@@ -66,6 +66,7 @@ struct SparseParams {
     unsigned int *items; int *item_count; long long item_stride; // per (scale, first column block b): items[(s*4+b)*item_stride + i] = cand*256 + slot*4 + ch
     float *ckf; double *cka; double *part; float *ckh;
     const float *zeros; // 3 * 4 * W floats of 0.0f: what sparse_v2_body prefetches for the group below the image
+    float *trash;       // 256 floats nobody reads: where the H pass's flush sends the stores of lanes that have nothing to store (its store instructions carry no predicate)
     // --dither: a candidate's pixels come from its own palette_map (k_dither, MODE 2) instead of the pack's win test; B's from bmap
     int use_maps, sub_size; uint32_t slot_ci; const uint8_t *maps, *mapsC4, *bmap, *bmapC4, *subC4, *tile_pal; // maps: + (k - k0) * W * H
     int s_first; // the general H and V bodies skip scales below this one (the wide scales run the bodies of kernels_sparse2.hpp)

@@ -48,15 +48,47 @@ namespace snes {
 // ---- H pass of changed groups, from their first changed column block -----------------------------------------------------
 // grid.y = item list (scale * kColBuckets + first block); block = one wave = 16 work items (candidate, slot, channel), a
 // lane quad = the four rows of an item.  Column quads g run from 16*block to W/4; iteration g consumes the inputs of quad g
-// (the "right" taps in[n+4]) and yields the outputs of quad g-1; the five-slot register ring keeps quads g-3..g+1.
+// (the "right" taps in[n+4]) and yields the outputs of quad g-1.
 // S0: scale 0 — the candidate's pixels come from the pack (win test) instead of an XYB plane.
 // bx / gx: the block's index and count among the blocks of its list (blockIdx.x / gridDim.x unless the caller remaps blocks)
+//
+// The memory pipeline (round 4).  The body is a chain of dependent iterations per wave, and until round 4 every iteration
+// waited for its own prefetch: the loads of the next quad sat under `if (g + 1 < G4)`, the stores of a finished 8-column run
+// under `if ((g & 1) == 0)` and behind per-lane predicates, so at every wait the compiler had to assume the path on which
+// nothing younger than the awaited load had been issued — `s_waitcnt vmcnt(0)` 49 times in the kernel, the wave parked for a
+// full memory round trip per column quad (VALUBusy 40 %).  Now every vector-memory instruction of the steady state is
+// issued on every path, so the counter values are static:
+//   * inputs are fetched TWO quads ahead into a six-slot register ring, unconditionally (the address is clamped to the last
+//     quad; a quad beyond the row is zeroed when it is consumed);
+//   * the loop is unrolled by six from an odd quad (iteration gs, which stages nothing, is peeled), so ring slots, the
+//     staging half and the flush positions are compile-time constants;
+//   * the flush reads its eight lines from LDS in one batch and stores them without predicates — a lane with nothing to
+//     store (no item, or a plane the launch does not write) aims at a scratch line (`trash`);
+//   * a block is ONE wave: LDS operations of a wave execute in order, so the staging needs no barrier, only the compiler
+//     kept from reordering (lds_order) — __syncthreads() also waited for every load and store in flight.
+// Same values operation for operation as before (sparse == dense, bit for bit: tests/test_gpu_parity.py).
 // LDS of one block (= one wave), shared by the two instantiations of the body (a block runs one of them; declared inside the
 // template each instantiation would take its own copy and the kernel would hold both: 32 KB per wave, five waves per CU)
 struct H2Shared {
     __attribute__((aligned(16))) float out[16 * (4 * 32 + 4)];  // staging: per item [plane][8 columns][4 rows] + pad
     long long hbase[16], xbase[16];                             // per item: float offset of its H output / XYB planes inside P.store, -1 = no item
 };
+__device__ __forceinline__ void lds_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } // one-wave blocks: program order is LDS order
+// colour indices of the four pixels of a column quad of row y at scale 0 (pa / pb: the quad's pack words — or, with --dither,
+// its map and subpalette-base words; bw: the word of the candidate's won-pixel bitmap that holds the quad's four bits)
+template <bool BASE>
+__device__ __forceinline__ void h2_resolve(const SparseParams &P, const uint4 pa, const uint4 pb, const uint32_t bw, const int g, const uint32_t crgb, uint32_t (&ci)[4]) {
+    if (P.use_maps) resolve4_maps(pa.x, pa.y, BASE ? 0xffffffffu : P.slot_ci, (uint32_t)P.ncol, ci);
+    else if (P.perceptual && !BASE) { // four consecutive pixels of a row: four consecutive bits (W = 256: a row is eight words)
+        const uint32_t b4 = (bw >> ((g & 7) << 2)) & 0xfu;
+        ci[0] = (b4 & 1u) ? (uint32_t)P.ncol : (pa.x >> 24); ci[1] = (b4 & 2u) ? (uint32_t)P.ncol : (pa.z >> 24);
+        ci[2] = (b4 & 4u) ? (uint32_t)P.ncol : (pb.x >> 24); ci[3] = (b4 & 8u) ? (uint32_t)P.ncol : (pb.z >> 24);
+    } else {
+        const uint32_t never = BASE ? 0u : 0xffffffffu; // thr & never == 0 for B: it wins nothing
+        ci[0] = sparse_ci(pa.x, pa.y & never, crgb, (uint32_t)P.ncol); ci[1] = sparse_ci(pa.z, pa.w & never, crgb, (uint32_t)P.ncol);
+        ci[2] = sparse_ci(pb.x, pb.y & never, crgb, (uint32_t)P.ncol); ci[3] = sparse_ci(pb.z, pb.w & never, crgb, (uint32_t)P.ncol);
+    }
+}
 // BASE: the launch is B's own H pass (every item is B's: no win test, and the block checkpoints are written) / the candidates'
 template <bool S0, bool BASE>
 __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int list, const int bx, const int gx, H2Shared &sh) {
@@ -78,35 +110,38 @@ __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int 
     if (bx * 16 >= count) return;
     if (S0) {
         for (int i = lane; i < 3 * lstr; i += 64) { const int c = i / lstr, j = i - c * lstr; s_lut[i] = P.pal_xyb[3 * j + c]; }
-        __syncthreads();
+        lds_order();
     }
     const float n2_0 = P.K.n2[0], n2_1 = P.K.n2[1], n2_2 = P.K.n2[2];
     const float mp_0 = -P.K.d1[0], mp_1 = -P.K.d1[1], mp_2 = -P.K.d1[2];
-    const int G4 = W >> 2, gs = cb << 4, gstart = gs >= 3 ? gs - 3 : 0; // three warm-up iterations refill the ring
+    const int G4 = W >> 2, gs = cb << 4; // first quad of the block: a multiple of 16
     const int r = lane & 3;
+    const int half = lane >> 5, fl = lane & 31, fp = fl >> 3, fc = fl & 7; // the flush: half-wave = item, lane = (plane, column) of the staged 8-column run
+    float *const trash = P.trash + (lane << 2);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i0 = bx * 16; i0 < count; i0 += gx * 16) { // grid-stride over item quads
         const int qi = i0 + (lane >> 2);
         const bool valid = qi < count;
         const unsigned int it = P.items[(size_t)list * P.item_stride + (valid ? qi : i0)];
         const int k = (int)(it >> 8), j = (int)((it >> 2) & 63u), ch = (int)(it & 3u);
-        constexpr bool is_base = BASE;
         const CandMeta *M = P.meta + k;
         const int y = 4 * (int)M->glist[P.S.goff[s] + j] + r;
         const size_t ns = (size_t)W * H;
-        const float cand_v = (S0 && !is_base) ? P.cand_tab[8 * (size_t)k + 3 + ch] : 0.0f;
-        const uint32_t crgb = (S0 && !is_base) ? __float_as_uint(P.cand_tab[8 * (size_t)k + 6]) : 0u;
-        const uint32_t never = is_base ? 0u : 0xffffffffu; // thr & never == 0 for B: it wins nothing
+        const float cand_v = (S0 && !BASE) ? P.cand_tab[8 * (size_t)k + 3 + ch] : 0.0f;
+        const uint32_t crgb = (S0 && !BASE) ? __float_as_uint(P.cand_tab[8 * (size_t)k + 6]) : 0u;
         const float4 *in1 = reinterpret_cast<const float4 *>(P.img1C4 + G.src_off[s] + (size_t)ch * ns) + y;   // C4: + g*H
         const uint4 *pk = S0 ? reinterpret_cast<const uint4 *>(P.packC4) + 2 * (size_t)y : nullptr;            // + g*2H
         const bool um = S0 && P.use_maps;
-        const uint32_t *mw = um ? reinterpret_cast<const uint32_t *>(is_base ? P.bmapC4 : P.mapsC4 + (size_t)(k - P.k0) * ns) + y : nullptr; // C4 bytes: word (g*H + y)
+        const uint32_t *mw = um ? reinterpret_cast<const uint32_t *>(BASE ? P.bmapC4 : P.mapsC4 + (size_t)(k - P.k0) * ns) + y : nullptr; // C4 bytes: word (g*H + y)
         const uint32_t *sw = um ? reinterpret_cast<const uint32_t *>(P.subC4) + y : nullptr;
+        // the row's words of the candidate's won-pixel bitmap (--perceptual-palettes); any readable words otherwise: the load is part of every prefetch
+        const uint32_t *bmrow = (S0 && P.perceptual && !BASE && !um) ? P.bitmap + (size_t)k * (G.W * G.H / 32) + (size_t)y * (W >> 5) : reinterpret_cast<const uint32_t *>(P.img1C4);
         const float4 *in2 = S0 ? nullptr
                                : reinterpret_cast<const float4 *>(P.store + (size_t)k * P.S.cand_stride + P.S.off_xybC[s] + (size_t)j * 12 * W + (size_t)ch * 4 * W) + r; // + g*4
-        __syncthreads(); // the previous round's flush has read the bases
+        lds_order(); // the previous round's flush has read the bases
         if (r == 0) {
             s_hbase[lane >> 2] = valid ? (long long)k * P.S.cand_stride + P.S.off_hout[s] + (long long)j * 36 * W + (long long)(ch * 3) * 4 * W : -1ll;
-            s_xbase[lane >> 2] = (long long)k * P.S.cand_stride + P.S.off_xybR[s] + (long long)j * 12 * W + (long long)ch * 4 * W;
+            s_xbase[lane >> 2] = valid ? (long long)k * P.S.cand_stride + P.S.off_xybR[s] + (long long)j * 12 * W + (long long)ch * 4 * W : -1ll;
         }
         float sa[3][3], sb[3][3];
         // B's state on entering the block: ckh[s][ch][block-1][18][row]
@@ -118,88 +153,97 @@ __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int 
                 sa[p][q] = gs > 0 ? ck[(size_t)(p * 6 + q) * H] : 0.0f;
                 sb[p][q] = gs > 0 ? ck[(size_t)(p * 6 + 3 + q) * H] : 0.0f;
             }
-        float4 r1[5], r2[5];
+        // six-slot ring: quad gs + t lives in slot t mod 6 (the three quads before gs in slots 3, 4, 5); at scale 0 the raw words
+        // of a quad wait in pa / pb / bw[t mod 3] until the quad is consumed
+        float4 r1[6], r2[6];
+        uint4 pa[3], pb[3]; uint32_t bw[3];
 #pragma unroll
-        for (int a = 0; a < 5; a++) { r1[a] = make_float4(0.f, 0.f, 0.f, 0.f); r2[a] = r1[a]; }
-        uint4 n_pa = make_uint4(0, 0, 0, 0), n_pb = n_pa;
-        r1[0] = in1[(size_t)gstart * H];
-        if (um) { n_pa.x = mw[(size_t)gstart * H]; n_pa.y = sw[(size_t)gstart * H]; }
-        else if (S0) { n_pa = pk[(size_t)gstart * H * 2]; n_pb = pk[(size_t)gstart * H * 2 + 1]; } else r2[0] = in2[(size_t)gstart * 4];
-        for (int g0 = gstart; g0 <= G4; g0 += 5) {
+        for (int a = 0; a < 6; a++) { r1[a] = zero4; r2[a] = zero4; }
 #pragma unroll
-            for (int u = 0; u < 5; u++) {
-                const int g = g0 + u;
-                if (g > G4) break;
-                const int un = (u + 1) % 5, ua = (u + 2) % 5, ub = (u + 3) % 5, ul = (u + 4) % 5; // slots of quads g+1, g-3, g-2, g-1
-                const uint4 c_pa = n_pa, c_pb = n_pb;
-                if (g + 1 < G4) {
-                    r1[un] = in1[(size_t)(g + 1) * H];
-                    if (um) { n_pa.x = mw[(size_t)(g + 1) * H]; n_pa.y = sw[(size_t)(g + 1) * H]; }
-                    else if (S0) { n_pa = pk[(size_t)(g + 1) * H * 2]; n_pb = pk[(size_t)(g + 1) * H * 2 + 1]; } else r2[un] = in2[(size_t)(g + 1) * 4];
-                } else { r1[un] = make_float4(0.f, 0.f, 0.f, 0.f); r2[un] = r1[un]; n_pa = make_uint4(0, 0, 0, 0); n_pb = n_pa; }
-                if (S0 && g < G4) {
-                    uint32_t c0, c1, c2, c3;
-                    if (P.use_maps) { // --dither: the candidate's (or B's) own palette_map; c_pa.x / .y hold the map and subpalette-base words
-                        uint32_t ci[4];
-                        resolve4_maps(c_pa.x, c_pa.y, is_base ? 0xffffffffu : P.slot_ci, (uint32_t)P.ncol, ci);
-                        c0 = ci[0]; c1 = ci[1]; c2 = ci[2]; c3 = ci[3];
-                    } else if (P.perceptual && !is_base) { // four consecutive pixels of row y: four consecutive bits of one bitmap word
-                        const int px0 = y * W + (g << 2);
-                        const uint32_t b4 = (P.bitmap[(size_t)k * (G.W * G.H / 32) + (px0 >> 5)] >> (px0 & 31)) & 0xfu;
-                        c0 = (b4 & 1u) ? (uint32_t)P.ncol : (c_pa.x >> 24); c1 = (b4 & 2u) ? (uint32_t)P.ncol : (c_pa.z >> 24);
-                        c2 = (b4 & 4u) ? (uint32_t)P.ncol : (c_pb.x >> 24); c3 = (b4 & 8u) ? (uint32_t)P.ncol : (c_pb.z >> 24);
-                    } else {
-                        c0 = sparse_ci(c_pa.x, c_pa.y & never, crgb, (uint32_t)P.ncol); c1 = sparse_ci(c_pa.z, c_pa.w & never, crgb, (uint32_t)P.ncol);
-                        c2 = sparse_ci(c_pb.x, c_pb.y & never, crgb, (uint32_t)P.ncol); c3 = sparse_ci(c_pb.z, c_pb.w & never, crgb, (uint32_t)P.ncol);
-                    }
-                    const float *lut = s_lut + ch * lstr;
-                    r2[u].x = c0 == (uint32_t)P.ncol ? cand_v : lut[c0]; r2[u].y = c1 == (uint32_t)P.ncol ? cand_v : lut[c1];
-                    r2[u].z = c2 == (uint32_t)P.ncol ? cand_v : lut[c2]; r2[u].w = c3 == (uint32_t)P.ncol ? cand_v : lut[c3];
-                }
-                if (g < gs) continue; // warm-up: the ring fills, the state is B's checkpoint
-                if (BASE && g > 0 && (g & 15) == 0 && g < G4 && valid) { // B: the state on entering block g/16
-                    float *co = P.ckh + P.S.off_ckh[s] + ((size_t)(ch * 3 + (g >> 4) - 1) * 18) * H + y;
+        for (int a = 0; a < 3; a++) { pa[a] = make_uint4(0, 0, 0, 0); pb[a] = pa[a]; bw[a] = 0u; }
+        auto fetch = [&](const int q, float4 &d1, float4 &d2, uint4 &wa, uint4 &wb, uint32_t &wbm) { // every load on every path (0 <= q < G4)
+            d1 = in1[(size_t)q * H];
+            if (S0) {
+                if (um) { wa.x = mw[(size_t)q * H]; wa.y = sw[(size_t)q * H]; } else { wa = pk[(size_t)q * H * 2]; wb = pk[(size_t)q * H * 2 + 1]; }
+                wbm = bmrow[q >> 3];
+            } else d2 = in2[(size_t)q * 4];
+        };
+        auto convert = [&](const int g, const uint4 wa, const uint4 wb, const uint32_t wbm, float4 &d2) { // scale 0: XYB of quad g
+            uint32_t ci[4];
+            h2_resolve<BASE>(P, wa, wb, wbm, g, crgb, ci);
+            const float *lut = s_lut + ch * lstr;
+            d2.x = ci[0] == (uint32_t)P.ncol ? cand_v : lut[ci[0]]; d2.y = ci[1] == (uint32_t)P.ncol ? cand_v : lut[ci[1]];
+            d2.z = ci[2] == (uint32_t)P.ncol ? cand_v : lut[ci[2]]; d2.w = ci[3] == (uint32_t)P.ncol ? cand_v : lut[ci[3]];
+        };
+        if (gs > 0) { // the three quads before the block refill the ring (the state is B's checkpoint)
+            uint4 ta[3], tb[3]; uint32_t tw[3];
 #pragma unroll
-                    for (int p = 0; p < 3; p++)
+            for (int a = 0; a < 3; a++) { ta[a] = make_uint4(0, 0, 0, 0); tb[a] = ta[a]; tw[a] = 0u; fetch(gs - 3 + a, r1[3 + a], r2[3 + a], ta[a], tb[a], tw[a]); }
+            if (S0) {
 #pragma unroll
-                        for (int q = 0; q < 3; q++) { co[(size_t)(p * 6 + q) * H] = sa[p][q]; co[(size_t)(p * 6 + 3 + q) * H] = sb[p][q]; }
-                }
-                const float v1[4] = {r1[u].x, r1[u].y, r1[u].z, r1[u].w}, v2[4] = {r2[u].x, r2[u].y, r2[u].z, r2[u].w};
-                const float l1[4] = {r1[ua].z, r1[ua].w, r1[ub].x, r1[ub].y}, l2[4] = {r2[ua].z, r2[ua].w, r2[ub].x, r2[ub].y};
-                float outp[3][4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const float s0 = l2[q] + v2[q];
-                    const float s1 = (l2[q] * l2[q]) + (v2[q] * v2[q]);
-                    const float s2 = (l1[q] * l2[q]) + (v1[q] * v2[q]);
-                    if ((q & 1) == 0) { SNES_HSTEP(s0, sa[0], sb[0], outp[0][q]) SNES_HSTEP(s1, sa[1], sb[1], outp[1][q]) SNES_HSTEP(s2, sa[2], sb[2], outp[2][q]) }
-                    else { SNES_HSTEP(s0, sb[0], sa[0], outp[0][q]) SNES_HSTEP(s1, sb[1], sa[1], outp[1][q]) SNES_HSTEP(s2, sb[2], sa[2], outp[2][q]) }
-                }
-                if (g > gs) { // outputs of quad g-1 (those of quad gs-1 are B's and stay unwritten): stage [plane][column % 8][row]
-                    float *so = s_out + (lane >> 2) * ISTR + (((g - 1) & 1) << 4) + r;
-#pragma unroll
-                    for (int p = 0; p < 3; p++) { so[p * PW + 0] = outp[p][0]; so[p * PW + 4] = outp[p][1]; so[p * PW + 8] = outp[p][2]; so[p * PW + 12] = outp[p][3]; }
-                    if (NP == 4) { so[3 * PW + 0] = r2[ul].x; so[3 * PW + 4] = r2[ul].y; so[3 * PW + 8] = r2[ul].z; so[3 * PW + 12] = r2[ul].w; }
-                    if ((g & 1) == 0) { // 8 columns complete (gs and W/4 are even): one store instruction per two items = their NP planes as 128-byte lines
-                        __syncthreads();
-                        const int x0 = (g - 2) << 2; // first column of the run
-                        const int half = lane >> 5, l = lane & 31, p = l >> 3, c = l & 7;
-                        // float offset of this lane's 16 bytes behind the item's base: plane p of the H output (XT4 block of x0), or the XYB plane (R4)
-                        const uint32_t o_l = (NP == 4 && p == 3) ? (uint32_t)(x0 << 2) + (uint32_t)(c << 2) : (uint32_t)p * 4u * (uint32_t)W + (uint32_t)((x0 >> 6) << 8) + (uint32_t)((x0 & 63) << 2) + (uint32_t)(c << 2);
-#pragma unroll 4
-                        for (int m = 0; m < 16; m += 2) {
-                            const long long hb = s_hbase[m + half];
-                            if (hb >= 0 && l < NP * 8) {
-                                const float4 v = *reinterpret_cast<const float4 *>(s_out + (m + half) * ISTR + l * 4);
-                                float *dst = P.store + ((NP == 4 && p == 3) ? s_xbase[m + half] : hb) + o_l;
-                                *reinterpret_cast<float4 *>(dst) = v;
-                            }
-                        }
-                        __syncthreads();
-                    }
-                }
+                for (int a = 0; a < 3; a++) convert(gs - 3 + a, ta[a], tb[a], tw[a], r2[3 + a]);
             }
         }
+        fetch(gs, r1[0], r2[0], pa[0], pb[0], bw[0]);
+        fetch(gs + 1, r1[1], r2[1], pa[1], pb[1], bw[1]);
+        // one iteration: T = (g - gs) mod 6, STAGE: the outputs of quad g-1 go to the staging area, FLUSH: an 8-column run is complete
+#define SNES_H2_ITER(T, STAGE, FLUSH)                                                                                         \
+        {                                                                                                                     \
+            constexpr int sl_ = (T) % 6, sf_ = ((T) + 2) % 6, ua_ = ((T) + 3) % 6, ub_ = ((T) + 4) % 6, ul_ = ((T) + 5) % 6; \
+            constexpr int wc_ = (T) % 3, wf_ = ((T) + 2) % 3;                                                                 \
+            { const int qf_ = min(g + 2, G4 - 1); fetch(qf_, r1[sf_], r2[sf_], pa[wf_], pb[wf_], bw[wf_]); }                  \
+            if (g >= G4) { r1[sl_] = zero4; r2[sl_] = zero4; }                                                                \
+            else if (S0) convert(g, pa[wc_], pb[wc_], bw[wc_], r2[sl_]);                                                      \
+            if (BASE && g > 0 && (g & 15) == 0 && g < G4 && valid) { /* B: the state on entering block g/16 */               \
+                float *co = P.ckh + P.S.off_ckh[s] + ((size_t)(ch * 3 + (g >> 4) - 1) * 18) * H + y;                          \
+                _Pragma("unroll") for (int p = 0; p < 3; p++)                                                                 \
+                    _Pragma("unroll") for (int q = 0; q < 3; q++) { co[(size_t)(p * 6 + q) * H] = sa[p][q]; co[(size_t)(p * 6 + 3 + q) * H] = sb[p][q]; } \
+            }                                                                                                                 \
+            const float v1[4] = {r1[sl_].x, r1[sl_].y, r1[sl_].z, r1[sl_].w}, v2[4] = {r2[sl_].x, r2[sl_].y, r2[sl_].z, r2[sl_].w};   \
+            const float l1[4] = {r1[ua_].z, r1[ua_].w, r1[ub_].x, r1[ub_].y}, l2[4] = {r2[ua_].z, r2[ua_].w, r2[ub_].x, r2[ub_].y};   \
+            float outp[3][4];                                                                                                 \
+            _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                                   \
+                const float s0 = l2[q] + v2[q];                                                                               \
+                const float s1 = (l2[q] * l2[q]) + (v2[q] * v2[q]);                                                           \
+                const float s2 = (l1[q] * l2[q]) + (v1[q] * v2[q]);                                                           \
+                if ((q & 1) == 0) { SNES_HSTEP(s0, sa[0], sb[0], outp[0][q]) SNES_HSTEP(s1, sa[1], sb[1], outp[1][q]) SNES_HSTEP(s2, sa[2], sb[2], outp[2][q]) } \
+                else { SNES_HSTEP(s0, sb[0], sa[0], outp[0][q]) SNES_HSTEP(s1, sb[1], sa[1], outp[1][q]) SNES_HSTEP(s2, sb[2], sa[2], outp[2][q]) }             \
+            }                                                                                                                 \
+            if (STAGE) { /* outputs of quad g-1 (those of quad gs-1 are B's and stay unwritten): stage [plane][column % 8][row] */ \
+                float *so = s_out + (lane >> 2) * ISTR + ((((T) + 1) & 1) << 4) + r; /* (g - 1) & 1: gs is even */            \
+                _Pragma("unroll") for (int p = 0; p < 3; p++) { so[p * PW + 0] = outp[p][0]; so[p * PW + 4] = outp[p][1]; so[p * PW + 8] = outp[p][2]; so[p * PW + 12] = outp[p][3]; } \
+                if (NP == 4) { so[3 * PW + 0] = r2[ul_].x; so[3 * PW + 4] = r2[ul_].y; so[3 * PW + 8] = r2[ul_].z; so[3 * PW + 12] = r2[ul_].w; } \
+            }                                                                                                                 \
+            if (FLUSH) { /* 8 columns complete: one store instruction per two items = their NP planes as 128-byte lines */    \
+                lds_order();                                                                                                  \
+                /* float offset of this lane's 16 bytes behind the item's base: plane fp of the H output (XT4: [x/64][x%64][row] = 4 x */ \
+                /* floats into the plane), or the XYB plane (R4: 4 x as well) */                                              \
+                const uint32_t o_l = ((NP == 4 && fp == 3) ? 0u : (uint32_t)fp * 4u * (uint32_t)W) + (uint32_t)((g - 2) << 4) + (uint32_t)(fc << 2); \
+                _Pragma("unroll") for (int mb = 0; mb < 16; mb += 8) {                                                        \
+                    float4 fv[4]; long long fb[4];                                                                            \
+                    _Pragma("unroll") for (int m = 0; m < 4; m++) {                                                           \
+                        const int im_ = mb + 2 * m + half;                                                                    \
+                        fv[m] = *reinterpret_cast<const float4 *>(s_out + im_ * ISTR + fl * 4);                               \
+                        fb[m] = (NP == 4 && fp == 3) ? s_xbase[im_] : s_hbase[im_];                                           \
+                    }                                                                                                         \
+                    _Pragma("unroll") for (int m = 0; m < 4; m++) {                                                           \
+                        float *dst = (fb[m] >= 0 && fl < NP * 8) ? P.store + fb[m] + o_l : trash;                             \
+                        *reinterpret_cast<float4 *>(dst) = fv[m];                                                             \
+                    }                                                                                                         \
+                }                                                                                                             \
+                asm volatile("" ::: "memory"); /* the staging area is rewritten from the next iteration on */                \
+            }                                                                                                                 \
+        }
+        { const int g = gs; SNES_H2_ITER(0, false, false) }
+        for (int g0 = gs + 1; g0 <= G4; g0 += 6) {
+            { const int g = g0; SNES_H2_ITER(1, true, false) }
+            { const int g = g0 + 1; if (g > G4) break; SNES_H2_ITER(2, true, true) }
+            { const int g = g0 + 2; if (g > G4) break; SNES_H2_ITER(3, true, false) }
+            { const int g = g0 + 3; if (g > G4) break; SNES_H2_ITER(4, true, true) }
+            { const int g = g0 + 4; if (g > G4) break; SNES_H2_ITER(5, true, false) }
+            { const int g = g0 + 5; if (g > G4) break; SNES_H2_ITER(6, true, true) }
+        }
+#undef SNES_H2_ITER
     }
 }
 
@@ -209,6 +253,7 @@ __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int 
 // every ~2.6 ns).  Here lane q < 3 of a quad carries plane q of the row (its own six state floats) and lane 3 stages the XYB
 // plane; the inputs are fetched by all four (one address: one request).  Same values operation for operation.  A wave holds
 // four items instead of sixteen: four times the waves for the same list, which is why long lists keep the other body.
+// The memory pipeline is sparse_h2_body's: every load and store of the steady state on every path.
 template <bool S0, bool BASE>
 __device__ __forceinline__ void sparse_h2q_body(const SparseParams &P, const int list, const int bx, const int gx, H2Shared &sh) {
     constexpr int NP = (S0 || !BASE) ? 4 : 3, PW = 32, ISTR = 4 * PW + 4; // (the XYB planes of B above scale 0 come from its downscale)
@@ -224,13 +269,16 @@ __device__ __forceinline__ void sparse_h2q_body(const SparseParams &P, const int
     if (bx * 4 >= count) return;
     if (S0) {
         for (int i = lane; i < 3 * lstr; i += 64) { const int c = i / lstr, j = i - c * lstr; s_lut[i] = P.pal_xyb[3 * j + c]; }
-        __syncthreads();
+        lds_order();
     }
     const int q = lane & 3, r = (lane >> 2) & 3, im = lane >> 4; // plane (3: the XYB plane), row of the group, item of the wave
     const int pl = q < 3 ? q : 0;
     const float n2_0 = P.K.n2[0], n2_1 = P.K.n2[1], n2_2 = P.K.n2[2];
     const float mp_0 = -P.K.d1[0], mp_1 = -P.K.d1[1], mp_2 = -P.K.d1[2];
-    const int G4 = W >> 2, gs = cb << 4, gstart = gs >= 3 ? gs - 3 : 0;
+    const int G4 = W >> 2, gs = cb << 4;
+    const int half = lane >> 5, fl = lane & 31, fp = fl >> 3, fc = fl & 7;
+    float *const trash = P.trash + (lane << 2);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i0 = bx * 4; i0 < count; i0 += gx * 4) {
         const int qi = i0 + im;
         const bool valid = qi < count;
@@ -241,18 +289,18 @@ __device__ __forceinline__ void sparse_h2q_body(const SparseParams &P, const int
         const size_t ns = (size_t)W * H;
         const float cand_v = (S0 && !BASE) ? P.cand_tab[8 * (size_t)k + 3 + ch] : 0.0f;
         const uint32_t crgb = (S0 && !BASE) ? __float_as_uint(P.cand_tab[8 * (size_t)k + 6]) : 0u;
-        const uint32_t never = BASE ? 0u : 0xffffffffu; // thr & never == 0 for B: it wins nothing
         const float4 *in1 = reinterpret_cast<const float4 *>(P.img1C4 + G.src_off[s] + (size_t)ch * ns) + y;
         const uint4 *pk = S0 ? reinterpret_cast<const uint4 *>(P.packC4) + 2 * (size_t)y : nullptr;
         const bool um = S0 && P.use_maps;
         const uint32_t *mw = um ? reinterpret_cast<const uint32_t *>(BASE ? P.bmapC4 : P.mapsC4 + (size_t)(k - P.k0) * ns) + y : nullptr;
         const uint32_t *sw = um ? reinterpret_cast<const uint32_t *>(P.subC4) + y : nullptr;
+        const uint32_t *bmrow = (S0 && P.perceptual && !BASE && !um) ? P.bitmap + (size_t)k * (G.W * G.H / 32) + (size_t)y * (W >> 5) : reinterpret_cast<const uint32_t *>(P.img1C4);
         const float4 *in2 = S0 ? nullptr
                                : reinterpret_cast<const float4 *>(P.store + (size_t)k * P.S.cand_stride + P.S.off_xybC[s] + (size_t)j * 12 * W + (size_t)ch * 4 * W) + r;
-        __syncthreads(); // the previous round's flush has read the bases
+        lds_order(); // the previous round's flush has read the bases
         if ((lane & 15) == 0) {
             s_hbase[im] = valid ? (long long)k * P.S.cand_stride + P.S.off_hout[s] + (long long)j * 36 * W + (long long)(ch * 3) * 4 * W : -1ll;
-            s_xbase[im] = (long long)k * P.S.cand_stride + P.S.off_xybR[s] + (long long)j * 12 * W + (long long)ch * 4 * W;
+            s_xbase[im] = valid ? (long long)k * P.S.cand_stride + P.S.off_xybR[s] + (long long)j * 12 * W + (long long)ch * 4 * W : -1ll;
         }
         float sa[3], sb[3]; // this lane's plane
         const float *ck = P.ckh + P.S.off_ckh[s] + ((size_t)(ch * 3 + (cb > 0 ? cb - 1 : 0)) * 18) * H + y;
@@ -261,91 +309,90 @@ __device__ __forceinline__ void sparse_h2q_body(const SparseParams &P, const int
             sa[e] = gs > 0 ? ck[(size_t)(pl * 6 + e) * H] : 0.0f;
             sb[e] = gs > 0 ? ck[(size_t)(pl * 6 + 3 + e) * H] : 0.0f;
         }
-        // six-slot ring: quads g-3 .. g+2; the inputs are fetched TWO quads ahead (a short list's waves are alone on their
-        // SIMDs: an iteration is a fraction of a memory round trip)
         float4 r1[6], r2[6];
+        uint4 pa[3], pb[3]; uint32_t bw[3];
 #pragma unroll
-        for (int a = 0; a < 6; a++) { r1[a] = make_float4(0.f, 0.f, 0.f, 0.f); r2[a] = r1[a]; }
-        const uint4 z4 = make_uint4(0, 0, 0, 0);
-        uint4 n_pa = z4, n_pb = z4, m_pa = z4, m_pb = z4; // pack (or map) words of quads g+1 and g+2
-        auto fetch = [&](int gg, float4 &d1, float4 &d2, uint4 &pa, uint4 &pb) {
-            if (gg < G4) {
-                d1 = in1[(size_t)gg * H];
-                if (um) { pa.x = mw[(size_t)gg * H]; pa.y = sw[(size_t)gg * H]; }
-                else if (S0) { pa = pk[(size_t)gg * H * 2]; pb = pk[(size_t)gg * H * 2 + 1]; } else d2 = in2[(size_t)gg * 4];
-            } else { d1 = make_float4(0.f, 0.f, 0.f, 0.f); d2 = d1; pa = z4; pb = z4; }
+        for (int a = 0; a < 6; a++) { r1[a] = zero4; r2[a] = zero4; }
+#pragma unroll
+        for (int a = 0; a < 3; a++) { pa[a] = make_uint4(0, 0, 0, 0); pb[a] = pa[a]; bw[a] = 0u; }
+        auto fetch = [&](const int qq, float4 &d1, float4 &d2, uint4 &wa, uint4 &wb, uint32_t &wbm) {
+            d1 = in1[(size_t)qq * H];
+            if (S0) {
+                if (um) { wa.x = mw[(size_t)qq * H]; wa.y = sw[(size_t)qq * H]; } else { wa = pk[(size_t)qq * H * 2]; wb = pk[(size_t)qq * H * 2 + 1]; }
+                wbm = bmrow[qq >> 3];
+            } else d2 = in2[(size_t)qq * 4];
         };
-        fetch(gstart, r1[0], r2[0], n_pa, n_pb);
-        fetch(gstart + 1, r1[1], r2[1], m_pa, m_pb);
-        for (int g0 = gstart; g0 <= G4; g0 += 6) {
+        auto convert = [&](const int g, const uint4 wa, const uint4 wb, const uint32_t wbm, float4 &d2) {
+            uint32_t ci[4];
+            h2_resolve<BASE>(P, wa, wb, wbm, g, crgb, ci);
+            const float *lut = s_lut + ch * lstr;
+            d2.x = ci[0] == (uint32_t)P.ncol ? cand_v : lut[ci[0]]; d2.y = ci[1] == (uint32_t)P.ncol ? cand_v : lut[ci[1]];
+            d2.z = ci[2] == (uint32_t)P.ncol ? cand_v : lut[ci[2]]; d2.w = ci[3] == (uint32_t)P.ncol ? cand_v : lut[ci[3]];
+        };
+        if (gs > 0) {
+            uint4 ta[3], tb[3]; uint32_t tw[3];
 #pragma unroll
-            for (int u = 0; u < 6; u++) {
-                const int g = g0 + u;
-                if (g > G4) break;
-                const int un2 = (u + 2) % 6, ua = (u + 3) % 6, ub = (u + 4) % 6, ul = (u + 5) % 6; // slots of quads g+2, g-3, g-2, g-1
-                const uint4 c_pa = n_pa, c_pb = n_pb;
-                n_pa = m_pa; n_pb = m_pb;
-                fetch(g + 2, r1[un2], r2[un2], m_pa, m_pb);
-                if (S0 && g < G4) {
-                    uint32_t c0, c1, c2, c3;
-                    if (P.use_maps) {
-                        uint32_t ci[4];
-                        resolve4_maps(c_pa.x, c_pa.y, BASE ? 0xffffffffu : P.slot_ci, (uint32_t)P.ncol, ci);
-                        c0 = ci[0]; c1 = ci[1]; c2 = ci[2]; c3 = ci[3];
-                    } else if (P.perceptual && !BASE) {
-                        const int px0 = y * W + (g << 2);
-                        const uint32_t b4 = (P.bitmap[(size_t)k * (G.W * G.H / 32) + (px0 >> 5)] >> (px0 & 31)) & 0xfu;
-                        c0 = (b4 & 1u) ? (uint32_t)P.ncol : (c_pa.x >> 24); c1 = (b4 & 2u) ? (uint32_t)P.ncol : (c_pa.z >> 24);
-                        c2 = (b4 & 4u) ? (uint32_t)P.ncol : (c_pb.x >> 24); c3 = (b4 & 8u) ? (uint32_t)P.ncol : (c_pb.z >> 24);
-                    } else {
-                        c0 = sparse_ci(c_pa.x, c_pa.y & never, crgb, (uint32_t)P.ncol); c1 = sparse_ci(c_pa.z, c_pa.w & never, crgb, (uint32_t)P.ncol);
-                        c2 = sparse_ci(c_pb.x, c_pb.y & never, crgb, (uint32_t)P.ncol); c3 = sparse_ci(c_pb.z, c_pb.w & never, crgb, (uint32_t)P.ncol);
-                    }
-                    const float *lut = s_lut + ch * lstr;
-                    r2[u].x = c0 == (uint32_t)P.ncol ? cand_v : lut[c0]; r2[u].y = c1 == (uint32_t)P.ncol ? cand_v : lut[c1];
-                    r2[u].z = c2 == (uint32_t)P.ncol ? cand_v : lut[c2]; r2[u].w = c3 == (uint32_t)P.ncol ? cand_v : lut[c3];
-                }
-                if (g < gs) continue;
-                if (BASE && q < 3 && g > 0 && (g & 15) == 0 && g < G4 && valid) { // B: the state of this plane on entering block g/16
-                    float *co = P.ckh + P.S.off_ckh[s] + ((size_t)(ch * 3 + (g >> 4) - 1) * 18) * H + y;
+            for (int a = 0; a < 3; a++) { ta[a] = make_uint4(0, 0, 0, 0); tb[a] = ta[a]; tw[a] = 0u; fetch(gs - 3 + a, r1[3 + a], r2[3 + a], ta[a], tb[a], tw[a]); }
+            if (S0) {
 #pragma unroll
-                    for (int e = 0; e < 3; e++) { co[(size_t)(pl * 6 + e) * H] = sa[e]; co[(size_t)(pl * 6 + 3 + e) * H] = sb[e]; }
-                }
-                const float v1[4] = {r1[u].x, r1[u].y, r1[u].z, r1[u].w}, v2[4] = {r2[u].x, r2[u].y, r2[u].z, r2[u].w};
-                const float l1[4] = {r1[ua].z, r1[ua].w, r1[ub].x, r1[ub].y}, l2[4] = {r2[ua].z, r2[ua].w, r2[ub].x, r2[ub].y};
-                float outp[4];
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    // this lane's plane: mu2 <- img2, s22 <- img2^2, s12 <- img1 * img2 (the same expressions as sparse_h2_body)
-                    const float s0 = l2[c] + v2[c];
-                    const float s1 = (l2[c] * l2[c]) + (v2[c] * v2[c]);
-                    const float s2 = (l1[c] * l2[c]) + (v1[c] * v2[c]);
-                    const float sum = q == 0 ? s0 : (q == 1 ? s1 : s2);
-                    if ((c & 1) == 0) { SNES_HSTEP(sum, sa, sb, outp[c]) } else { SNES_HSTEP(sum, sb, sa, outp[c]) }
-                }
-                if (g > gs) {
-                    float *so = s_out + im * ISTR + (((g - 1) & 1) << 4) + r + q * PW;
-                    if (q < 3) { so[0] = outp[0]; so[4] = outp[1]; so[8] = outp[2]; so[12] = outp[3]; }
-                    else if (NP == 4) { so[0] = r2[ul].x; so[4] = r2[ul].y; so[8] = r2[ul].z; so[12] = r2[ul].w; }
-                    if ((g & 1) == 0) {
-                        __syncthreads();
-                        const int x0 = (g - 2) << 2;
-                        const int half = lane >> 5, l = lane & 31, p = l >> 3, c = l & 7;
-                        const uint32_t o_l = (p == 3) ? (uint32_t)(x0 << 2) + (uint32_t)(c << 2) : (uint32_t)p * 4u * (uint32_t)W + (uint32_t)((x0 >> 6) << 8) + (uint32_t)((x0 & 63) << 2) + (uint32_t)(c << 2);
-#pragma unroll
-                        for (int m = 0; m < 4; m += 2) {
-                            const long long hb = s_hbase[m + half];
-                            if (hb >= 0 && l < NP * 8) {
-                                const float4 v = *reinterpret_cast<const float4 *>(s_out + (m + half) * ISTR + l * 4);
-                                float *dst = P.store + ((p == 3) ? s_xbase[m + half] : hb) + o_l;
-                                *reinterpret_cast<float4 *>(dst) = v;
-                            }
-                        }
-                        __syncthreads();
-                    }
-                }
+                for (int a = 0; a < 3; a++) convert(gs - 3 + a, ta[a], tb[a], tw[a], r2[3 + a]);
             }
         }
+        fetch(gs, r1[0], r2[0], pa[0], pb[0], bw[0]);
+        fetch(gs + 1, r1[1], r2[1], pa[1], pb[1], bw[1]);
+#define SNES_H2Q_ITER(T, STAGE, FLUSH)                                                                                        \
+        {                                                                                                                     \
+            constexpr int sl_ = (T) % 6, sf_ = ((T) + 2) % 6, ua_ = ((T) + 3) % 6, ub_ = ((T) + 4) % 6, ul_ = ((T) + 5) % 6; \
+            constexpr int wc_ = (T) % 3, wf_ = ((T) + 2) % 3;                                                                 \
+            { const int qf_ = min(g + 2, G4 - 1); fetch(qf_, r1[sf_], r2[sf_], pa[wf_], pb[wf_], bw[wf_]); }                  \
+            if (g >= G4) { r1[sl_] = zero4; r2[sl_] = zero4; }                                                                \
+            else if (S0) convert(g, pa[wc_], pb[wc_], bw[wc_], r2[sl_]);                                                      \
+            if (BASE && q < 3 && g > 0 && (g & 15) == 0 && g < G4 && valid) { /* B: the state of this plane on entering block g/16 */ \
+                float *co = P.ckh + P.S.off_ckh[s] + ((size_t)(ch * 3 + (g >> 4) - 1) * 18) * H + y;                          \
+                _Pragma("unroll") for (int e = 0; e < 3; e++) { co[(size_t)(pl * 6 + e) * H] = sa[e]; co[(size_t)(pl * 6 + 3 + e) * H] = sb[e]; } \
+            }                                                                                                                 \
+            const float v1[4] = {r1[sl_].x, r1[sl_].y, r1[sl_].z, r1[sl_].w}, v2[4] = {r2[sl_].x, r2[sl_].y, r2[sl_].z, r2[sl_].w};   \
+            const float l1[4] = {r1[ua_].z, r1[ua_].w, r1[ub_].x, r1[ub_].y}, l2[4] = {r2[ua_].z, r2[ua_].w, r2[ub_].x, r2[ub_].y};   \
+            float outp[4];                                                                                                    \
+            _Pragma("unroll") for (int c = 0; c < 4; c++) {                                                                   \
+                /* this lane's plane: mu2 <- img2, s22 <- img2^2, s12 <- img1 * img2 (the same expressions as sparse_h2_body) */ \
+                const float s0 = l2[c] + v2[c];                                                                               \
+                const float s1 = (l2[c] * l2[c]) + (v2[c] * v2[c]);                                                           \
+                const float s2 = (l1[c] * l2[c]) + (v1[c] * v2[c]);                                                           \
+                const float sum = q == 0 ? s0 : (q == 1 ? s1 : s2);                                                           \
+                if ((c & 1) == 0) { SNES_HSTEP(sum, sa, sb, outp[c]) } else { SNES_HSTEP(sum, sb, sa, outp[c]) }              \
+            }                                                                                                                 \
+            if (STAGE) {                                                                                                      \
+                float *so = s_out + im * ISTR + ((((T) + 1) & 1) << 4) + r + q * PW;                                          \
+                if (q < 3) { so[0] = outp[0]; so[4] = outp[1]; so[8] = outp[2]; so[12] = outp[3]; }                           \
+                else if (NP == 4) { so[0] = r2[ul_].x; so[4] = r2[ul_].y; so[8] = r2[ul_].z; so[12] = r2[ul_].w; }            \
+            }                                                                                                                 \
+            if (FLUSH) {                                                                                                      \
+                lds_order();                                                                                                  \
+                const uint32_t o_l = ((fp == 3) ? 0u : (uint32_t)fp * 4u * (uint32_t)W) + (uint32_t)((g - 2) << 4) + (uint32_t)(fc << 2); \
+                float4 fv[2]; long long fb[2];                                                                                \
+                _Pragma("unroll") for (int m = 0; m < 2; m++) {                                                               \
+                    const int im_ = 2 * m + half;                                                                             \
+                    fv[m] = *reinterpret_cast<const float4 *>(s_out + im_ * ISTR + fl * 4);                                   \
+                    fb[m] = (fp == 3) ? s_xbase[im_] : s_hbase[im_];                                                          \
+                }                                                                                                             \
+                _Pragma("unroll") for (int m = 0; m < 2; m++) {                                                               \
+                    float *dst = (fb[m] >= 0 && fl < NP * 8) ? P.store + fb[m] + o_l : trash;                                 \
+                    *reinterpret_cast<float4 *>(dst) = fv[m];                                                                 \
+                }                                                                                                             \
+                asm volatile("" ::: "memory");                                                                               \
+            }                                                                                                                 \
+        }
+        { const int g = gs; SNES_H2Q_ITER(0, false, false) }
+        for (int g0 = gs + 1; g0 <= G4; g0 += 6) {
+            { const int g = g0; SNES_H2Q_ITER(1, true, false) }
+            { const int g = g0 + 1; if (g > G4) break; SNES_H2Q_ITER(2, true, true) }
+            { const int g = g0 + 2; if (g > G4) break; SNES_H2Q_ITER(3, true, false) }
+            { const int g = g0 + 3; if (g > G4) break; SNES_H2Q_ITER(4, true, true) }
+            { const int g = g0 + 4; if (g > G4) break; SNES_H2Q_ITER(5, true, false) }
+            { const int g = g0 + 5; if (g > G4) break; SNES_H2Q_ITER(6, true, true) }
+        }
+#undef SNES_H2Q_ITER
     }
 }
 template <bool BASE>
