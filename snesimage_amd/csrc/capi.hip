@@ -6,7 +6,6 @@
 #include "kernels_fast.hpp"
 #include "kernels_sparse.hpp"
 #include "kernels_sparse2.hpp"
-#include "kernels_narrow.hpp"
 #include "kernels_batch.hpp"
 
 #include <hip/hip_runtime.h>
@@ -149,7 +148,6 @@ struct snesimage_ctx {
     // Row-sparse scoring (kernels_sparse.hpp): one storage array for every lane's candidates plus the base image B
     struct Sparse {
         bool lpt = true; // V pass in descending sweep length (SNES_LPT=0: as listed)
-        bool narrow = true; // the scales narrower than 64 pixels in one dense, LDS-resident kernel per candidate (kernels_narrow.hpp; SNES_NARROW=0: the general group-sparse bodies, resumed from B's narrow sweeps)
         bool down1 = true; // scale 1 of the candidates' downscale in a kernel of its own, one block per changed group (SNES_DOWN1=0: inside k_sparse_down)
         bool counters_cleared = false; // k_prep cleared B's counters for the current pack
         uint32_t h2q_max = 512; // longest list that takes k_sparse_h2q (SNES_H2Q_MAX; 0 = never)
@@ -537,19 +535,6 @@ SparseParams sparse_params(snesimage_ctx *c, uint32_t lane) {
     return P;
 }
 
-// k_sparse_narrow's planes in LDS (75 KB at 256 rows: beyond the 64 KB a kernel may take without asking)
-static size_t narrow_lds(const snesimage_ctx *c) {
-    int s_first = 0;
-    for (; s_first < c->G.nscales && c->G.sw[s_first] >= 64; s_first++) {}
-    const size_t bytes = narrow_lds_bytes(c->G, s_first);
-    static std::atomic<size_t> granted{0};
-    if (bytes > granted.load(std::memory_order_relaxed)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_narrow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kb_sparse_narrow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        granted.store(bytes, std::memory_order_relaxed);
-    }
-    return bytes;
-}
 static size_t h2_lds(const snesimage_ctx *c) { return sizeof(float) * 3 * (size_t)(c->ncol + 2); } // k_sparse_h2's palette table in LDS
 
 // B of the current slot: compact list of contested pixels, then the pipeline once with checkpoints (main stream)
@@ -613,12 +598,10 @@ int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si) {
         // sweeps follow and are awaited by the candidates' narrow V pass at the very end of the launch group
         if (P.s_first > 0) hipLaunchKernelGGL(k_sparse_v2_base, dim3(3, (unsigned)P.s_first), dim3(256), 0, bs, P);
         if (sp.side) HIPCHK(hipEventRecord(sp.ev_base_done, bs));
-        if (!sp.narrow) { // (k_sparse_narrow scores the narrow scales densely: B needs no sweeps there)
-            if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((G.sh[P.s_first] / 4 * 3 + 15) / 16), (unsigned)((G.nscales - P.s_first) * kColBuckets)), dim3(64), 0, bs, P);
-            if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_v_base_narrow, dim3(3, (unsigned)(G.nscales - P.s_first)), dim3(256), 0, bs, P);
-        }
+        if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((G.sh[P.s_first] / 4 * 3 + 15) / 16), (unsigned)((G.nscales - P.s_first) * kColBuckets)), dim3(64), 0, bs, P);
+        if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_v_base_narrow, dim3(3, (unsigned)(G.nscales - P.s_first)), dim3(256), 0, bs, P);
         HIPCHK(hipGetLastError());
-        if (sp.side && !sp.narrow) HIPCHK(hipEventRecord(sp.ev_base_narrow, bs));
+        if (sp.side) HIPCHK(hipEventRecord(sp.ev_base_narrow, bs));
         if (c->dither && sp.side && sp.ahead.dpack) { // B of the scheduler's next slot, behind this B's sweeps on their stream
             auto &ah = sp.ahead;
             int ni = si + 1, np = sp_idx;
@@ -686,14 +669,11 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
         HIPCHK(hipMemsetAsync(sp.bitmap + (size_t)P.k0 * (c->npx / 32), 0, sizeof(uint32_t) * (c->npx / 32) * nc, stream));
         hipLaunchKernelGGL(k_sparse_scan_lab, dim3(nc), dim3(256), 0, stream, P);
     } else hipLaunchKernelGGL(k_sparse_scan, dim3((nc + 15) / 16), dim3(1024), 0, stream, P);
-    const int s_down_hi = sp.narrow ? P.s_first : G.nscales; // (the narrow scales' downscale is k_sparse_narrow's phase D)
     if (sp.down1 && G.nscales > 2) { // scale 1 one block per changed group (the scan's item lists name them), then the scales that do depend on each other
         size_t gd = (size_t)nc * 8; if (gd > 32768) gd = 32768; // (~6 changed groups per candidate; grid-stride beyond)
         hipLaunchKernelGGL(k_sparse_down1, dim3((unsigned)gd), dim3(256), 0, stream, P);
-        if (s_down_hi > 2) hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P, 2, s_down_hi);
-    } else hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P, 1, s_down_hi);
-    // the narrow scales, whole, one block per candidate: they need the scan, the rows above and B's downscale — nothing of B's sweeps
-    if (sp.narrow && P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_narrow, dim3(nc), dim3(192), narrow_lds(c), stream, P);
+        hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P, -2);
+    } else hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P, 0);
     if (sp.side) HIPCHK(hipStreamWaitEvent(stream, sp.ev_base_h, 0)); // B's H-pass checkpoints (a short list gets here before B's sweep is through)
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[1], stream)); // ev[1]..ev[2]: the candidates' H pass alone (the wait for B's sweep is before it)
     { size_t gx = ((size_t)nc * (G.sh[0] / 4) * 3 + 15) / 16; if (gx > sp.hgrid) gx = sp.hgrid; // grid-stride over the item quads
@@ -702,7 +682,7 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
           hipLaunchKernelGGL(k_sparse_h2q, dim3((unsigned)gq, (unsigned)(P.s_first * kColBuckets)), dim3(64), h2_lds(c), stream, P);
       } else
       hipLaunchKernelGGL(k_sparse_h2, dim3((unsigned)gx, (unsigned)(P.s_first * kColBuckets)), dim3(64), h2_lds(c), stream, P);
-      if (!sp.narrow && P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((gx + 7) / 8), (unsigned)((G.nscales - P.s_first) * kColBuckets)), dim3(64), 0, stream, P); }
+      if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((gx + 7) / 8), (unsigned)((G.nscales - P.s_first) * kColBuckets)), dim3(64), 0, stream, P); }
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[2], stream));
     if (sp.side || stream != c->stream) HIPCHK(hipStreamWaitEvent(stream, sp.side ? sp.ev_base_done : c->ev_ready, 0)); // checkpoints and H output of B
     if (c->sp.lpt && nc > 512) { // (a short list's blocks are all resident at once: their order is immaterial)
@@ -711,10 +691,8 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[3], stream));
     hipLaunchKernelGGL(k_sparse_v2, dim3(nc * 3, (unsigned)P.s_first), dim3(256), 0, stream, P);
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[4], stream)); // ev[3]..ev[4]: k_sparse_v2 alone
-    if (!sp.narrow) {
-        if (sp.side) HIPCHK(hipStreamWaitEvent(stream, sp.ev_base_narrow, 0)); // B's narrow-scale sweeps
-        if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_v, dim3((nc * 3 + 7) / 8, (unsigned)(G.nscales - P.s_first)), dim3(256), 0, stream, P); // narrow scales: >= 8 pairs per block
-    }
+    if (sp.side) HIPCHK(hipStreamWaitEvent(stream, sp.ev_base_narrow, 0)); // B's narrow-scale sweeps
+    if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_v, dim3((nc * 3 + 7) / 8, (unsigned)(G.nscales - P.s_first)), dim3(256), 0, stream, P); // narrow scales: >= 8 pairs per block
     hipLaunchKernelGGL(k_final_score, dim3((nc + 63) / 64), dim3(64), 0, stream, sp.part + (size_t)P.k0 * G.nscales * 18, (int)nc, G, d_errors, err_stride, err_offset, P.item_count, (int)kItemLists);
     if (c->dither) { // the lane remembers the map of its best candidate so far: the commit adopts the winner's instead of dithering again
         uint8_t *bm = lane == 0 ? c->d_bestmap : c->extra[lane - 1].d_bestmap; BestRec *br = lane == 0 ? c->d_bestrec : c->extra[lane - 1].d_bestrec;
@@ -943,7 +921,6 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     if (const char *e = getenv("SNES_BASE_STREAM")) c->sp.side = atoi(e) != 0;
     if (const char *e = getenv("SNES_LPT")) c->sp.lpt = atoi(e) != 0;
     if (const char *e = getenv("SNES_DOWN1")) c->sp.down1 = atoi(e) != 0;
-    if (const char *e = getenv("SNES_NARROW")) c->sp.narrow = atoi(e) != 0;
     if (const char *e = getenv("SNES_DITHER4")) c->dither4 = atoi(e) != 0;
     if (const char *e = getenv("SNES_DITHERW")) c->ditherw = atoi(e) != 0;
     if (const char *e = getenv("SNES_DITHER_AHEAD")) c->sp.ahead.on = atoi(e) != 0;

@@ -3,7 +3,7 @@
 // arguments sit in a device array instead of the kernel's own argument block.  Every image of a batch has the same
 // geometry and the same number of candidates, so one grid shape serves them all; nothing is shared between images.
 #pragma once
-#include "kernels_narrow.hpp"
+#include "kernels_sparse2.hpp"
 
 namespace snes {
 
@@ -64,8 +64,7 @@ template <int SUB> __global__ __launch_bounds__(256) void kb_dither_runw(const B
 __global__ __launch_bounds__(1024) void kb_dither_diff(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; dither_diff_body(a.Pc); }
 __global__ __launch_bounds__(1024) void kb_sparse_scan(const BatchArgs *__restrict__ A, int base, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_scan_body(base ? a.Pb : a.Pc); }
 __global__ __launch_bounds__(256) void kb_base_down(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; base_down_body(a.Pb); }
-__global__ __launch_bounds__(256) void kb_sparse_down(const BatchArgs *__restrict__ A, int s_lo, int s_hi, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_down_body(a.Pc, s_lo, s_hi, bb.x); }
-__global__ __launch_bounds__(192) void kb_sparse_narrow(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_narrow_body(a.Pc, bb.x); } // the narrow scales of every candidate: kernels_narrow.hpp
+__global__ __launch_bounds__(256) void kb_sparse_down(const BatchArgs *__restrict__ A, int only_scale, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_down_body(a.Pc, only_scale, bb.x); }
 __global__ __launch_bounds__(256) void kb_sparse_down1(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_down1_body(a.Pc, bb.x, (int)gridDim.x); }
 __global__ void kb_candidate_tables(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; candidate_tables_body(a.cand, a.n, a.eotf, a.cand_tab); }
 __global__ void kb_candidate_lab(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; candidate_lab_body(a.cand_tab, a.n, a.lab_eotf, a.cand_lab); }

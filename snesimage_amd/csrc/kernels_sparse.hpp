@@ -455,7 +455,7 @@ __device__ __forceinline__ void dither_diff_body(const SparseParams &P) {
 // ---- downscale chain + XYB on changed groups only -------------------------------------------------------
 // base: grid.x blocks share the rows of each scale (launched once per scale, P.ncand = scale to do);
 // candidates: one block per candidate walks the scales itself.
-__device__ __forceinline__ void sparse_down_body(const SparseParams &P, const int s_lo, const int s_hi_, const int bx) { // scales [s_lo, s_hi_) (clamped to the image's); bx: blockIdx.x unless the caller remaps blocks
+__device__ __forceinline__ void sparse_down_body(const SparseParams &P, int only_scale, const int bx) { // bx: blockIdx.x unless the caller remaps blocks
     __shared__ float s_lin[256 * 3];
     const Geom &G = P.G;
     const int t = threadIdx.x;
@@ -470,7 +470,7 @@ __device__ __forceinline__ void sparse_down_body(const SparseParams &P, const in
     const CandMeta *M = P.meta + k;
     float *mine = P.store + (size_t)k * P.S.cand_stride;
     const float *basep = P.store + (size_t)P.base * P.S.cand_stride;
-    const int s_hi = s_hi_ < G.nscales ? s_hi_ : G.nscales;
+    const int s_lo = only_scale > 0 ? only_scale : (only_scale < 0 ? -only_scale : 1), s_hi = only_scale > 0 ? only_scale + 1 : G.nscales; // only_scale < 0: from scale -only_scale on
     const int part0 = is_base ? bx : 0, nparts = is_base ? (int)gridDim.x : 1;
     for (int s = s_lo; s < s_hi; s++) {
         const int Ws = G.sw[s], Wp = G.sw[s - 1];
@@ -1137,7 +1137,7 @@ __global__ __launch_bounds__(1024) void k_sparse_scan(SparseParams P) { sparse_s
 __global__ __launch_bounds__(1024) void k_dither_first(SparseParams P) { dither_first_body(P); }
 __global__ __launch_bounds__(256) void k_dither_first_lab(SparseParams P) { dither_first_lab_body(P); }
 __global__ __launch_bounds__(1024) void k_dither_diff(SparseParams P) { dither_diff_body(P); }
-__global__ __launch_bounds__(256) void k_sparse_down(SparseParams P, int s_lo, int s_hi) { sparse_down_body(P, s_lo, s_hi, (int)blockIdx.x); }
+__global__ __launch_bounds__(256) void k_sparse_down(SparseParams P, int only_scale) { sparse_down_body(P, only_scale, (int)blockIdx.x); }
 __global__ __launch_bounds__(256) void k_sparse_down1(SparseParams P) { sparse_down1_body(P, (int)blockIdx.x, (int)gridDim.x); }
 __global__ __launch_bounds__(256) void k_base_down(SparseParams P) { base_down_body(P); }
 __global__ __launch_bounds__(64) void k_sparse_h(SparseParams P) { sparse_h_body(P); }
