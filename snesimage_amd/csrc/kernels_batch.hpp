@@ -62,7 +62,8 @@ template <int SUB> __global__ __launch_bounds__(512) void kb_dither_run4(const B
 template <int SUB> __global__ __launch_bounds__(128) void kb_dither_run(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; if ((int)blockIdx.x < a.n) dither_body<false, SUB, 2>(a.Dc, (int)blockIdx.x); }
 template <int SUB> __global__ __launch_bounds__(256) void kb_dither_runw(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; ditherw_body<SUB>(a.Dc, (int)blockIdx.x, a.n); }
 __global__ __launch_bounds__(1024) void kb_dither_diff(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; dither_diff_body(a.Pc); }
-__global__ __launch_bounds__(1024) void kb_sparse_scan(const BatchArgs *__restrict__ A, int base, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_scan_body(base ? a.Pb : a.Pc); }
+__global__ __launch_bounds__(1024) void kb_sparse_scan(const BatchArgs *__restrict__ A, int base, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_scan_body<1>(base ? a.Pb : a.Pc); }
+__global__ __launch_bounds__(1024) void kb_sparse_scan4(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_scan_body<4>(a.Pc); } // four waves per candidate
 __global__ __launch_bounds__(256) void kb_base_down(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; base_down_body(a.Pb); }
 __global__ __launch_bounds__(256) void kb_sparse_down(const BatchArgs *__restrict__ A, int only_scale, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_down_body(a.Pc, only_scale, bb.x); }
 __global__ __launch_bounds__(256) void kb_sparse_down1(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_down1_body(a.Pc, bb.x, (int)gridDim.x); }

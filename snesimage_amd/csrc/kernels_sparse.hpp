@@ -266,15 +266,22 @@ __device__ __forceinline__ void sparse_scan_lab_body(const SparseParams &P) {
 // (and min-reduces x) with shuffles.  A scale has at most 64 groups, so its changed set is one 64-bit
 // word: scale s+1 is the pairwise OR of scale s, a group's slot is a popcount.  No LDS, no barriers.
 constexpr int kScanTile = 6144; // contested pixels staged in LDS per pass (the BASELINE slot has ~6.8 k)
+// WPC: waves per candidate.  A wave walks the list in steps of 64: ~107 dependent iterations for the BASELINE slot, whatever
+// the launch holds — 35-50 us, a tenth of a short call or a short slot window.  With WPC = 4 a candidate's list is dealt to
+// four waves (a block = four candidates; masks, counts and the groups' leftmost columns combined through LDS, as
+// dither_diff_body does): a quarter of the chain for four times the blocks, which is what lists that do not fill the chip want.
+template <int WPC>
 __device__ __forceinline__ void sparse_scan_body(const SparseParams &P) {
-    // 16 waves = 16 candidates per block share one LDS copy of the slot's contested-pixel list
+    constexpr int CPB = 16 / WPC; // candidates per block: sixteen waves share one LDS copy of the slot's contested-pixel list
     __shared__ uint32_t s_rgb[kScanTile], s_thr[kScanTile];
     __shared__ unsigned short s_px[kScanTile]; // x | (y>>2) << 8 would lose x precision: keep x (8 bit) and group (6 bit)
-    __shared__ int s_gx[16][64]; // per wave: smallest won x of every scale-0 group
+    __shared__ int s_gx[CPB][64]; // per candidate: smallest won x of every scale-0 group
+    __shared__ unsigned long long s_mask[16];
+    __shared__ int s_xmin[16], s_won[16];
     const Geom &G = P.G;
-    const int lane = threadIdx.x & 63;
-    s_gx[threadIdx.x >> 6][lane] = 0x7fff;
-    const int wi = (int)blockIdx.x * 16 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, cw = w / WPC, part = w % WPC;
+    if (part == 0) s_gx[cw][lane] = 0x7fff;
+    const int wi = (int)blockIdx.x * CPB + cw;
     const bool live = P.is_base ? (wi == 0) : (wi < P.ncand);
     const int k = P.is_base ? P.base : P.k0 + (live ? wi : 0);
     unsigned long long mask = 0ull; int xmin = G.W, won = 0;
@@ -292,10 +299,10 @@ __device__ __forceinline__ void sparse_scan_body(const SparseParams &P) {
             }
             __syncthreads();
             if (live) {
-                for (int i = lane; i < nt; i += 64) {
+                for (int i = part * 64 + lane; i < nt; i += 64 * WPC) {
                     if (red_mean_key(crgb, s_rgb[i]) < s_thr[i]) {
                         const int px = s_px[i];
-                        atomicMin(&s_gx[threadIdx.x >> 6][px >> 8], px & 255);
+                        atomicMin(&s_gx[cw][px >> 8], px & 255);
                         mask |= 1ull << (px >> 8);
                         xmin = min(xmin, px & 255);
                         won++;
@@ -310,7 +317,16 @@ __device__ __forceinline__ void sparse_scan_body(const SparseParams &P) {
             won += __shfl_xor(won, o);
         }
     }
-    scan_publish<16>(P, k, live, mask, xmin, won, P.is_base ? 0 : s_gx[threadIdx.x >> 6][lane]);
+    if (WPC > 1) { // the candidate's waves combine what they saw
+        if (lane == 0) { s_mask[w] = mask; s_xmin[w] = xmin; s_won[w] = won; }
+        __syncthreads();
+        if (!P.is_base) {
+            mask = 0ull; xmin = G.W; won = 0;
+#pragma unroll
+            for (int q = 0; q < WPC; q++) { mask |= s_mask[cw * WPC + q]; xmin = min(xmin, s_xmin[cw * WPC + q]); won += s_won[cw * WPC + q]; }
+        }
+    }
+    scan_publish<16>(P, k, live && part == 0, mask, xmin, won, P.is_base ? 0 : s_gx[cw][lane]); // the candidate's first wave publishes
 }
 
 // ---- --dither: where does a candidate first differ from B? -----------------------------------------------------
@@ -1133,7 +1149,8 @@ __global__ __launch_bounds__(1024) void k_sparse_order(SparseParams P, int *__re
 
 // ---- kernel entry points of the bodies above ----
 __global__ __launch_bounds__(256) void k_sparse_scan_lab(SparseParams P) { sparse_scan_lab_body(P); }
-__global__ __launch_bounds__(1024) void k_sparse_scan(SparseParams P) { sparse_scan_body(P); }
+__global__ __launch_bounds__(1024) void k_sparse_scan(SparseParams P) { sparse_scan_body<1>(P); }
+__global__ __launch_bounds__(1024) void k_sparse_scan4(SparseParams P) { sparse_scan_body<4>(P); } // short lists: four waves per candidate
 __global__ __launch_bounds__(1024) void k_dither_first(SparseParams P) { dither_first_body(P); }
 __global__ __launch_bounds__(256) void k_dither_first_lab(SparseParams P) { dither_first_lab_body(P); }
 __global__ __launch_bounds__(1024) void k_dither_diff(SparseParams P) { dither_diff_body(P); }
