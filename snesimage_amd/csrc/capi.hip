@@ -153,7 +153,7 @@ struct snesimage_ctx {
         uint32_t h2q_max = 512; // longest list that takes k_sparse_h2q (SNES_H2Q_MAX; 0 = never)
         uint32_t scan4_max = 2048; // longest list whose scan deals a candidate's contested pixels to four waves (SNES_SCAN4_MAX; 0 = never)
         uint32_t hgrid = 8192; // most blocks per scale of k_sparse_h (grid-stride beyond)
-        bool enabled = false, side = true; uint32_t min_n = 64; uint32_t cap = 0; // cap = candidates per lane the arrays were sized for
+        bool enabled = false, side = true; uint32_t min_n = 1; uint32_t cap = 0; // min_n: shortest list that takes the group-sparse path (SNES_SPARSE_MIN; until round 4: 64 — a channel sweep's 32 candidates, or a rank's share of a 64-candidate call, went the dense way: 0.35 ms against 0.27, 1.7 ms with --perceptual-palettes) // cap = candidates per lane the arrays were sized for
         SparseGeom S{};
         float *store = nullptr, *cand_tab = nullptr, *cand_lab = nullptr, *ckf = nullptr, *ckh = nullptr; long long zeros_off = 0; uint32_t *bitmap = nullptr; double *cka = nullptr, *part = nullptr;
         CandMeta *meta = nullptr; unsigned int *items = nullptr; int *item_count = nullptr; long long item_stride = 0; int *order = nullptr, *first = nullptr;
@@ -695,7 +695,7 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[4], stream)); // ev[3]..ev[4]: k_sparse_v2 alone
     if (sp.side) HIPCHK(hipStreamWaitEvent(stream, sp.ev_base_narrow, 0)); // B's narrow-scale sweeps
     if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_v, dim3((nc * 3 + 7) / 8, (unsigned)(G.nscales - P.s_first)), dim3(256), 0, stream, P); // narrow scales: >= 8 pairs per block
-    hipLaunchKernelGGL(k_final_score, dim3((nc + 63) / 64), dim3(64), 0, stream, sp.part + (size_t)P.k0 * G.nscales * 18, (int)nc, G, d_errors, err_stride, err_offset, P.item_count, (int)kItemLists);
+    hipLaunchKernelGGL(k_final_score_wave, dim3((nc + 3) / 4), dim3(256), 0, stream, sp.part + (size_t)P.k0 * G.nscales * 18, (int)nc, G, d_errors, err_stride, err_offset, P.item_count, (int)kItemLists);
     if (c->dither) { // the lane remembers the map of its best candidate so far: the commit adopts the winner's instead of dithering again
         uint8_t *bm = lane == 0 ? c->d_bestmap : c->extra[lane - 1].d_bestmap; BestRec *br = lane == 0 ? c->d_bestrec : c->extra[lane - 1].d_bestrec;
         hipLaunchKernelGGL(k_keep_best, dim3(1), dim3(1024), 0, stream, d_errors, err_stride, err_offset, (int)nc, P.maps, (int)c->npx, br, bm);

@@ -714,11 +714,52 @@ __device__ __forceinline__ void final_score_body(const double *__restrict__ part
     errors[(size_t)err_offset + (size_t)c * err_stride] = 100.0 - ssim;
 }
 
+// The same with a wave per candidate (round 4).  One thread per candidate walks 18 (channel, scale) records of six sums one
+// after the other — ~110 dependent loads and square roots, 11-14 us whatever the launch holds: a fixed piece of every call
+// and every slot window.  Here lane l < 3 * nscales forms the six terms of record l (channel l / nscales, scale l % nscales:
+// the order the chain consumes them in), and the chain itself — the SAME 108 fused multiply-adds in the same order — runs
+// on values fetched lane by lane with v_readlane.
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void final_score_wave_body(const double *__restrict__ part, int ncand, const Geom &G, double *__restrict__ errors, int err_stride, int err_offset, int *__restrict__ zero, int nzero) {
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (zero && gt < nzero) zero[gt] = 0; // the launch group's work-item counters, ready for the lane's next chunk
+    const int lane = threadIdx.x & 63, c = __builtin_amdgcn_readfirstlane(gt >> 6);
+    if (c >= ncand) return;
+    const int ns = G.nscales, npair = 3 * ns;
+    double term[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (lane < npair) {
+        const int ch = lane / ns, s = lane - ch * ns;
+        const double *p = part + (((size_t)c * ns + s) * 3 + ch) * 6;
+        const double opp = 1.0 / (double)((size_t)G.sw[s] * G.sh[s]);
+        term[0] = opp * p[0]; term[1] = opp * p[2]; term[2] = opp * p[4];                                  // avg_ssim[0], avg_edge[0], avg_edge[2]
+        term[3] = sqrt(sqrt(opp * p[1])); term[4] = sqrt(sqrt(opp * p[3])); term[5] = sqrt(sqrt(opp * p[5])); // avg_ssim[1], avg_edge[1], avg_edge[3]
+    }
+    double ssim = 0.0;
+    int i = 0;
+    for (int l = 0; l < npair; l++) {
+#pragma unroll
+        for (int t = 0; t < 6; t++) { ssim = fma(kSsim2Weight[i], fabs(readlane_f64(term[t], l)), ssim); i++; }
+    }
+    if (lane != 0) return;
+    ssim *= SSIM2_SCORE_SCALE;
+    ssim = fma(SSIM2_SCORE_C3 * ssim * ssim, ssim, fma(SSIM2_SCORE_C1, ssim, SSIM2_SCORE_C2 * ssim * ssim));
+    if (ssim > 0.0) ssim = fma(pow(ssim, SSIM2_SCORE_EXP), SSIM2_SCORE_GAIN, SSIM2_SCORE_MAX);
+    else ssim = SSIM2_SCORE_MAX;
+    errors[(size_t)err_offset + (size_t)c * err_stride] = 100.0 - ssim;
+}
+
 // ---- kernel entry points of the bodies above (kernels_batch.hpp holds the many-images flavours) ----
 __global__ void k_candidate_tables(const uint8_t *__restrict__ rgb5, int n, const float *__restrict__ eotf, float *__restrict__ cand_tab) { candidate_tables_body(rgb5, n, eotf, cand_tab); }
 __global__ __launch_bounds__(256) void k_prep(PrepParams P) { prep_body(P); }
 __global__ void k_final_score(const double *__restrict__ part, int ncand, Geom G, double *__restrict__ errors, int err_stride, int err_offset, int *__restrict__ zero = nullptr, int nzero = 0) {
     final_score_body(part, ncand, G, errors, err_stride, err_offset, zero, nzero);
+}
+// a wave per candidate, four candidates per block: grid (ncand + 3) / 4, 256 threads
+__global__ __launch_bounds__(256) void k_final_score_wave(const double *__restrict__ part, int ncand, Geom G, double *__restrict__ errors, int err_stride, int err_offset, int *__restrict__ zero = nullptr, int nzero = 0) {
+    final_score_wave_body(part, ncand, G, errors, err_stride, err_offset, zero, nzero);
 }
 
 } // namespace snes

@@ -17,10 +17,14 @@ struct BatchArgs {
     // --dither (slot windows): Floyd-Steinberg of the call's base image B (k_dither4 MODE 1: the slot's entry stands in for
     // entry j0 of its subpalette, colour bcolor -> table row btab) and the candidates' resumed runs (MODE 2)
     DitherParams Db, Dc; const unsigned long long *win_pack; const uint8_t *bcolor; float *btab; int *zero; int nzero; uint8_t *map;
+    int dead_base; // slot windows: see SNES_BATCH_IMG (the launch's first member carries it)
 };
 
-// `dead` (optional device flag): nonzero = this launch belongs to a slot window that an earlier window has voided: leave at once
-#define SNES_BATCH_IMG if (dead && *dead) return; const BatchArgs &a = A[blockIdx.z]
+// `dead` (optional): the sequence number of the last slot window whose commit changed the palette.  A window is built on the
+// assumption that the windows in flight before it — numbers dead_base and up — accept nothing: once *dead >= dead_base that is
+// false, the window is void and its launches leave at once.  Numbers only grow, so the word is never reset (until round 4 it was a
+// flag, cleared by a memset in front of every window that followed an acceptance: ~20 us of host and queue time per window).
+#define SNES_BATCH_IMG if (dead && *dead >= A[0].dead_base) return; const BatchArgs &a = A[blockIdx.z]
 // XCD-aware block -> (image, x, y) mapping for the heavy stages.  Blocks are dealt round-robin over the chip's 8 XCDs, each
 // with its own L2; with blockIdx.z = image every XCD would see every image and fetch its base image, checkpoints and source
 // planes (~20 MB per image) once per XCD (PMC: 2.25 MB fetched per candidate in the V pass against 0.37 MB in single-image
@@ -38,7 +42,7 @@ __device__ __forceinline__ BatchBlock batch_block() {
     b.x = rem % X; b.y = rem / X;
     return b;
 }
-#define SNES_BATCH_XCD if (dead && *dead) return; const BatchBlock bb = batch_block(); const BatchArgs &a = A[bb.img]
+#define SNES_BATCH_XCD if (dead && *dead >= A[0].dead_base) return; const BatchBlock bb = batch_block(); const BatchArgs &a = A[bb.img]
 __global__ void kb_gen_candidates(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; gen_candidates_body(a.method, a.n, a.key, a.colors_in, a.slot, a.channel, a.cand, 0, 1, nullptr, nullptr); }
 __global__ __launch_bounds__(256) void kb_prep(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; prep_body(a.prep); }
 __global__ __launch_bounds__(256) void kb_build_plist(const BatchArgs *__restrict__ A, const int *__restrict__ dead) {
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) void kb_sparse_v_base(const BatchArgs *__restr
 __global__ __launch_bounds__(256, 1) void kb_sparse_v_base_narrow(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_v_base_narrow_dispatch(a.Pb); }
 __global__ __launch_bounds__(1024) void kb_sparse_order(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_order_body(a.Pc, const_cast<int *>(a.Pc.order)); }
 __global__ __launch_bounds__(256, 2) void kb_sparse_v(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_v_body<false, 2, 2>(a.Pc, (int)blockIdx.y + a.Pc.s_first); }
-__global__ void kb_final_score(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; final_score_body(a.part, a.n, a.Pc.G, a.errors, 1, 0, a.Pc.item_count, (int)kItemLists); }
+__global__ __launch_bounds__(256) void kb_final_score(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; final_score_wave_body(a.part, a.n, a.Pc.G, a.errors, 1, 0, a.Pc.item_count, (int)kItemLists); } // grid.x = (n + 3) / 4: a wave per candidate
 __global__ __launch_bounds__(256) void kb_commit(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; commit_body(a.errors, a.n, a.cand, a.colors, a.slot, a.nes, a.inc_err, a.last, a.T); }
 // --dither, image batches: lib.rs:237's optimize() of the committed palette is the winner's own resumed run (every candidate of
 // an image is scored on this device, so it is always at hand); nothing accepted: the stored map stands
@@ -113,8 +117,8 @@ constexpr int kMaxWindow = 1024; // calls per window over all ranks
 
 // The candidate lists of all K calls (every rank generates all of them: the commit needs the winner's colour wherever it
 // was scored) and the error vector preset to +inf (a rank fills in the calls it owns; the others arrive by min-all-reduce).
-__global__ void kw_gen_candidates(const WindowSlot *__restrict__ S, const uint8_t *__restrict__ colors, uint8_t *__restrict__ cand, double *__restrict__ errors, int stride, const int *__restrict__ dead) {
-    if (*dead) return;
+__global__ void kw_gen_candidates(const WindowSlot *__restrict__ S, const uint8_t *__restrict__ colors, uint8_t *__restrict__ cand, double *__restrict__ errors, int stride, const int *__restrict__ dead, int dead_base) {
+    if (*dead >= dead_base) return;
     const WindowSlot w = S[blockIdx.y];
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < stride) errors[(size_t)blockIdx.y * stride + k] = __longlong_as_double(0x7ff0000000000000ll);
@@ -126,8 +130,8 @@ __global__ void kw_gen_candidates(const WindowSlot *__restrict__ S, const uint8_
 // behind the first call that changed the state (a candidate accepted; for the NES method, which always takes its table
 // argmin, a colour that differs from the current one).  log[j] = what snesimage_last_step would report after call j.
 __global__ __launch_bounds__(1024) void kw_commit(const WindowSlot *__restrict__ S, int K, int stride, const double *__restrict__ errors, const uint8_t *__restrict__ cand, uint8_t *__restrict__ colors,
-                                                 double *__restrict__ inc_err, StepResult *__restrict__ last, PaletteTables T, WindowResult *__restrict__ res, StepResult *__restrict__ log, int *__restrict__ dead) {
-    if (*dead) { if (threadIdx.x == 0) { res->consumed = 0; res->accepted = 0; } return; } // voided by an earlier window's commit: nothing of this one happened
+                                                 double *__restrict__ inc_err, StepResult *__restrict__ last, PaletteTables T, WindowResult *__restrict__ res, StepResult *__restrict__ log, int *__restrict__ dead, int dead_base, int seq) {
+    if (*dead >= dead_base) { if (threadIdx.x == 0) { res->consumed = 0; res->accepted = 0; } return; } // voided by an earlier window's commit: nothing of this one happened
     __shared__ double s_e[kMaxWindow];
     __shared__ int s_k[kMaxWindow];
     const int l16 = threadIdx.x & 15, q = threadIdx.x >> 4; // sixteen lanes per call: 64 calls at a time (the loads' latency is what this loop costs)
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(1024) void kw_commit(const WindowSlot *__restrict__
         }
     }
     res->consumed = consumed; res->accepted = accepted;
-    if (accepted) *dead = 1; // windows already enqueued behind this one were built for the old palette
+    if (accepted) *dead = seq; // windows already enqueued behind this one were built for the old palette
     if (consumed) *last = log[consumed - 1];
 }
 
