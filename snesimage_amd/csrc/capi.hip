@@ -151,6 +151,7 @@ struct snesimage_ctx {
         bool down1 = true; // scale 1 of the candidates' downscale in a kernel of its own, one block per changed group (SNES_DOWN1=0: inside k_sparse_down)
         bool counters_cleared = false; // k_prep cleared B's counters for the current pack
         uint32_t h2q_max = 512; // longest list that takes k_sparse_h2q (SNES_H2Q_MAX; 0 = never)
+        bool vsplit = true; // B's wide V sweep with recurrences and maps on two waves (k_sparse_v2_base_split; SNES_VSPLIT=0: one wave does both)
         uint32_t scan4_max = 2048; // longest list whose scan deals a candidate's contested pixels to four waves (SNES_SCAN4_MAX; 0 = never)
         uint32_t hgrid = 8192; // most blocks per scale of k_sparse_h (grid-stride beyond)
         bool enabled = false, side = true; uint32_t min_n = 1; uint32_t cap = 0; // min_n: shortest list that takes the group-sparse path (SNES_SPARSE_MIN; until round 4: 64 — a channel sweep's 32 candidates, or a rank's share of a 64-candidate call, went the dense way: 0.35 ms against 0.27, 1.7 ms with --perceptual-palettes) // cap = candidates per lane the arrays were sized for
@@ -597,7 +598,8 @@ int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si) {
         if (sp.side) HIPCHK(hipEventRecord(sp.ev_base_h, bs)); // the candidates' H pass resumes from the block checkpoints this launch leaves
         // the wide scales' V sweep first: the candidates' V pass (the bulk of a call) waits for it alone; the narrow scales'
         // sweeps follow and are awaited by the candidates' narrow V pass at the very end of the launch group
-        if (P.s_first > 0) hipLaunchKernelGGL(k_sparse_v2_base, dim3(3, (unsigned)P.s_first), dim3(256), 0, bs, P);
+        if (P.s_first > 0 && sp.vsplit) hipLaunchKernelGGL(k_sparse_v2_base_split, dim3((unsigned)(G.W >> 6), 3, (unsigned)P.s_first), dim3(128), 0, bs, P); // two waves per 64 columns: recurrences | maps and sums
+        else if (P.s_first > 0) hipLaunchKernelGGL(k_sparse_v2_base, dim3(3, (unsigned)P.s_first), dim3(256), 0, bs, P);
         if (sp.side) HIPCHK(hipEventRecord(sp.ev_base_done, bs));
         if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((G.sh[P.s_first] / 4 * 3 + 15) / 16), (unsigned)((G.nscales - P.s_first) * kColBuckets)), dim3(64), 0, bs, P);
         if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_v_base_narrow, dim3(3, (unsigned)(G.nscales - P.s_first)), dim3(256), 0, bs, P);
@@ -928,6 +930,7 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     if (const char *e = getenv("SNES_DITHER_AHEAD")) c->sp.ahead.on = atoi(e) != 0;
     if (const char *e = getenv("SNES_DITHER_REC")) c->dither_rec = atoi(e) != 0;
     if (const char *e = getenv("SNES_DITHER4_MAX")) { int v = atoi(e); if (v >= 0) c->dither4_max = (uint32_t)v; }
+    if (const char *e = getenv("SNES_VSPLIT")) c->sp.vsplit = atoi(e) != 0;
     if (const char *e = getenv("SNES_SCAN4_MAX")) { int v = atoi(e); if (v >= 0) c->sp.scan4_max = (uint32_t)v; }
     if (const char *e = getenv("SNES_H2Q_MAX")) { int v = atoi(e); if (v >= 0) c->sp.h2q_max = (uint32_t)v; }
     if (const char *e = getenv("SNES_HGRID")) { int v = atoi(e); if (v >= 1) c->sp.hgrid = (uint32_t)v; }

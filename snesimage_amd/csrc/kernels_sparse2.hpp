@@ -610,6 +610,113 @@ __device__ __forceinline__ void sparse_v2_body(const SparseParams &P, const int 
         for (int q = 0; q < 6; q++) o[q] = red[t][q];
     }
 }
+// ---- B's V sweep with the work of a column split over two waves (round 4) ---------------------------------------------------
+// sparse_v2_body<true> sweeps a single image: 21 waves in all, each alone on its SIMD, 65 dependent group iterations of ~245
+// vector instructions at the widest scale — a wave alone issues an instruction every ~4.6 ns there (binary64 among them):
+// 75 us, the longest piece of the fixed chain of a call once the candidates' own stages are short.  Here a block is the 64
+// columns of one (channel, scale) and holds TWO waves: wave R runs the three recurrences (vertical_pass, 120 instructions per
+// group iteration) and leaves the twelve outputs per column in LDS; wave M, one iteration behind, forms the maps and the
+// pooling sums from them (maps_accumulate, ~125).  Same operations on the same values in the same order — the recurrence
+// state and the sums are simply held by different waves — and the same checkpoint records: record g = R's state before its
+// iteration g (ckf) and M's sums before the maps of row group g-1 (cka); record H/4 + 1 = the final sums.
+// One barrier per iteration (s_barrier behind an LDS-only wait: __syncthreads() would also drain the loads in flight).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void sparse_v2_base_split_body(const SparseParams &P, const int s, const int ch, const int cb) { // cb: 64-column block of the scale
+    __shared__ __attribute__((aligned(16))) float s_x[2][3][64][4]; // [iteration parity][plane][column][row of the group]
+    const Geom &G = P.G;
+    const int W = uni(G.sw[s]), H = uni(G.sh[s]), H4 = H >> 2;
+    const int lane = threadIdx.x & 63;
+    const bool is_r = uni((int)(threadIdx.x >> 6)) == 0;
+    const int xw = cb << 6;
+    const size_t ns = (size_t)W * H;
+    const float *store_b = P.store + (size_t)P.base * P.S.cand_stride;
+    const uint32_t l16 = (uint32_t)lane << 4, l32 = (uint32_t)lane << 5;
+    const uint32_t W16 = (uint32_t)W * 16u; // bytes per (plane, group): 4 W floats
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (is_r) {
+        const rsrc_t h_b = make_rsrc(store_b + P.S.off_hout[s] + (size_t)(ch * 3) * 4 * W + ((size_t)(xw >> 6) << 8));
+        const rsrc_t h_zero = make_rsrc(P.zeros);
+        const float n2_0 = P.K.n2[0], n2_1 = P.K.n2[1], n2_2 = P.K.n2[2];
+        const float d1_0 = P.K.d1[0], d1_1 = P.K.d1[1], d1_2 = P.K.d1[2];
+        float sa[3][3], sb[3][3];
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) { sa[p][q] = 0.0f; sb[p][q] = 0.0f; }
+        float *ck_f = P.ckf + P.S.off_ckf[s] + ((size_t)ch * (H4 + 2)) * 18 * W + xw + lane;
+        float4 ring[3][3]; // [plane][group mod 3]: groups g-3, g-2 (tails) and the one being read
+        float4 nxt[3];
+#pragma unroll
+        for (int p = 0; p < 3; p++) { ring[p][0] = zero4; ring[p][1] = zero4; ring[p][2] = zero4; }
+#define SNES_V2S_HLOAD(GG, DST) { const int gg_ = (GG); const bool below_ = gg_ >= H4; const rsrc_t r_ = below_ ? h_zero : h_b; const uint32_t so_ = below_ ? 0u : (uint32_t)gg_ * 9u * W16; \
+            DST[0] = buf_ld4(r_, l16, so_); DST[1] = buf_ld4(r_, l16, so_ + W16); DST[2] = buf_ld4(r_, l16, so_ + 2u * W16); }
+        SNES_V2S_HLOAD(0, nxt)
+#define SNES_V2S_RITER(T) /* T = g mod 3 */                                                                                  \
+        {                                                                                                                     \
+            constexpr int u_ = (T) % 3, ux_ = ((T) + 1) % 3;                                                                  \
+            _Pragma("unroll") for (int p = 0; p < 3; p++)                                                                     \
+                _Pragma("unroll") for (int q = 0; q < 3; q++) { ck_f[(size_t)(p * 6 + q) * W] = sa[p][q]; ck_f[(size_t)(p * 6 + 3 + q) * W] = sb[p][q]; } \
+            ck_f += (size_t)18 * W;                                                                                           \
+            float4 cur[3] = {nxt[0], nxt[1], nxt[2]};                                                                         \
+            SNES_V2S_HLOAD(g + 1, nxt)                                                                                        \
+            _Pragma("unroll") for (int p = 0; p < 3; p++) {                                                                   \
+                const float4 tz = ring[p][u_], tx = ring[p][ux_]; /* group g-3 (second half), group g-2 (first half) */       \
+                float4 o;                                                                                                     \
+                SNES_VSTEP(tz.z + cur[p].x, sa[p], sb[p], o.x)                                                                \
+                SNES_VSTEP(tz.w + cur[p].y, sb[p], sa[p], o.y)                                                                \
+                SNES_VSTEP(tx.x + cur[p].z, sa[p], sb[p], o.z)                                                                \
+                SNES_VSTEP(tx.y + cur[p].w, sb[p], sa[p], o.w)                                                                \
+                ring[p][u_] = cur[p];                                                                                         \
+                *reinterpret_cast<float4 *>(&s_x[g & 1][p][lane][0]) = o;                                                     \
+            }                                                                                                                 \
+        }
+        for (int g0 = 0; g0 <= H4 + 1; g0 += 3) { // steps 0 .. H4+1: R works on steps 0 .. H4, every step ends at the barrier
+            { const int g = g0; if (g <= H4) SNES_V2S_RITER(0) lds_barrier(); }
+            { const int g = g0 + 1; if (g > H4 + 1) break; if (g <= H4) SNES_V2S_RITER(1) lds_barrier(); }
+            { const int g = g0 + 2; if (g > H4 + 1) break; if (g <= H4) SNES_V2S_RITER(2) lds_barrier(); }
+        }
+#undef SNES_V2S_RITER
+#undef SNES_V2S_HLOAD
+    } else {
+        const rsrc_t x_b = make_rsrc(store_b + P.S.off_xybR[s] + (size_t)ch * 4 * W + (size_t)xw * 4);
+        const rsrc_t m1_b = make_rsrc(P.mu1R4 + G.src_off[s] + (size_t)ch * ns + (size_t)xw * 4);
+        const rsrc_t sd1_b = make_rsrc(P.sd1R4 + G.src_off[s] + (size_t)ch * ns + (size_t)xw * 4);
+        const rsrc_t a1_b = make_rsrc(P.a1R4 + G.src_off[s] + (size_t)ch * ns + (size_t)xw * 4);
+        const rsrc_t r1_b = make_rsrc(P.r1R4 + G.src_off[s] + (size_t)ch * ns + (size_t)xw * 4);
+        double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double *ck_a = P.cka + P.S.off_cka[s] + ((size_t)ch * (H4 + 2)) * 6 * W + xw + lane;
+        // the map inputs of row group gm, fetched an iteration ahead
+        float4 n_m1, n_sd1, n_a1, n_x; double2 n_ra, n_rb;
+#define SNES_V2S_MLOAD(GM) { const uint32_t go_ = (uint32_t)(GM) * W16; n_m1 = buf_ld4(m1_b, l16, go_); n_sd1 = buf_ld4(sd1_b, l16, go_); n_a1 = buf_ld4(a1_b, l16, go_); \
+            n_ra = buf_ld2d(r1_b, l32, 2u * go_); n_rb = buf_ld2d(r1_b, l32 + 16u, 2u * go_); n_x = buf_ld4(x_b, l16, (uint32_t)(GM) * 3u * W16); }
+        SNES_V2S_MLOAD(0)
+        for (int t = 0; t <= H4 + 1; t++) { // step t: the maps of R's iteration g = t - 1, i.e. of row group t - 2
+            if (t >= 1) {
+                const int g = t - 1;
+#pragma unroll
+                for (int q = 0; q < 6; q++) ck_a[(size_t)q * W] = acc[q]; // record g: the sums before the maps of row group g-1
+                ck_a += (size_t)6 * W;
+                if (g >= 1) {
+                    const float4 c_m1 = n_m1, c_sd1 = n_sd1, c_a1 = n_a1, c_x = n_x; const double2 c_ra = n_ra, c_rb = n_rb;
+                    { const int gn = g < H4 ? g : H4 - 1; SNES_V2S_MLOAD(gn) } // group g's, for the next step (clamped: unused behind the last)
+                    const float4 o0 = *reinterpret_cast<const float4 *>(&s_x[g & 1][0][lane][0]), o1 = *reinterpret_cast<const float4 *>(&s_x[g & 1][1][lane][0]),
+                                 o2 = *reinterpret_cast<const float4 *>(&s_x[g & 1][2][lane][0]);
+                    const float m1v[4] = {c_m1.x, c_m1.y, c_m1.z, c_m1.w}, sd1v[4] = {c_sd1.x, c_sd1.y, c_sd1.z, c_sd1.w};
+                    const float a1v[4] = {c_a1.x, c_a1.y, c_a1.z, c_a1.w}, i2v[4] = {c_x.x, c_x.y, c_x.z, c_x.w};
+                    const double r1v[4] = {c_ra.x, c_ra.y, c_rb.x, c_rb.y};
+                    const float p0[4] = {o0.x, o0.y, o0.z, o0.w}, p1[4] = {o1.x, o1.y, o1.z, o1.w}, p2[4] = {o2.x, o2.y, o2.z, o2.w};
+#pragma unroll
+                    for (int q = 0; q < 4; q++) maps_accumulate(acc, m1v[q], sd1v[q], a1v[q], r1v[q], p0[q], p1[q], p2[q], i2v[q]);
+                }
+            }
+            lds_barrier();
+        }
+#undef SNES_V2S_MLOAD
+#pragma unroll
+        for (int q = 0; q < 6; q++) ck_a[(size_t)q * W] = acc[q]; // final record (H4 + 1): the pooling sums of the whole column
+    }
+}
+
 #undef SNES_HSTEP
 #undef SNES_VSTEP
 
@@ -628,6 +735,8 @@ __global__ __launch_bounds__(64) void k_sparse_h2_base(SparseParams P) { sparse_
 __global__ __launch_bounds__(256, 5) void k_sparse_v2(SparseParams P) { if ((int)blockIdx.y < P.G.nscales && P.G.sw[blockIdx.y] >= 64) sparse_v2_body<false>(P, (int)blockIdx.y, (int)blockIdx.x); }
 // B: the wide scales in this body (grid.y = scale), the narrow ones in the general one (grid.y = scale - s_first), two launches:
 // one kernel holding both bodies would take the larger register allocation for every block
+// B, split: grid.x = 64-column block (W / 64 of the widest scale), grid.y = channel, grid.z = scale; 128 threads
+__global__ __launch_bounds__(128) void k_sparse_v2_base_split(SparseParams P) { const int s = (int)blockIdx.z; if (s < P.G.nscales && P.G.sw[s] >= 64 && (int)blockIdx.x < (P.G.sw[s] >> 6)) sparse_v2_base_split_body(P, s, (int)blockIdx.y, (int)blockIdx.x); }
 __global__ __launch_bounds__(256) void k_sparse_v2_base(SparseParams P) { if ((int)blockIdx.y < P.G.nscales && P.G.sw[blockIdx.y] >= 64) sparse_v2_body<true>(P, (int)blockIdx.y, (int)blockIdx.x); }
 __device__ __forceinline__ void sparse_v_base_narrow_dispatch(const SparseParams &P) { const int s = (int)blockIdx.y + P.s_first; if (s < P.G.nscales) sparse_v_body<false, 0, 1>(P, s); }
 __global__ __launch_bounds__(256, 1) void k_sparse_v_base_narrow(SparseParams P) { sparse_v_base_narrow_dispatch(P); }
