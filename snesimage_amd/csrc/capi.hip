@@ -151,6 +151,7 @@ struct snesimage_ctx {
         bool down1 = true; // scale 1 of the candidates' downscale in a kernel of its own, one block per changed group (SNES_DOWN1=0: inside k_sparse_down)
         bool counters_cleared = false; // k_prep cleared B's counters for the current pack
         uint32_t h2q_max = 512; // longest list that takes k_sparse_h2q (SNES_H2Q_MAX; 0 = never)
+        uint32_t down1_grid = 32768; // most blocks of k_sparse_down1 (SNES_DOWN1_GRID)
         bool vsplit = true; // B's wide V sweep with recurrences and maps on two waves (k_sparse_v2_base_split; SNES_VSPLIT=0: one wave does both)
         uint32_t scan4_max = 2048; // longest list whose scan deals a candidate's contested pixels to four waves (SNES_SCAN4_MAX; 0 = never)
         uint32_t hgrid = 8192; // most blocks per scale of k_sparse_h (grid-stride beyond)
@@ -674,7 +675,7 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     } else if (nc <= sp.scan4_max) hipLaunchKernelGGL(k_sparse_scan4, dim3((nc + 3) / 4), dim3(1024), 0, stream, P); // a list that leaves CUs idle: four waves per candidate, a quarter of the chain
     else hipLaunchKernelGGL(k_sparse_scan, dim3((nc + 15) / 16), dim3(1024), 0, stream, P);
     if (sp.down1 && G.nscales > 2) { // scale 1 one block per changed group (the scan's item lists name them), then the scales that do depend on each other
-        size_t gd = (size_t)nc * 8; if (gd > 32768) gd = 32768; // (~6 changed groups per candidate; grid-stride beyond)
+        size_t gd = (size_t)nc * 8; if (gd > sp.down1_grid) gd = sp.down1_grid; // (~6 changed groups per candidate; grid-stride beyond)
         hipLaunchKernelGGL(k_sparse_down1, dim3((unsigned)gd), dim3(256), 0, stream, P);
         hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P, -2);
     } else hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P, 0);
@@ -930,6 +931,7 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     if (const char *e = getenv("SNES_DITHER_AHEAD")) c->sp.ahead.on = atoi(e) != 0;
     if (const char *e = getenv("SNES_DITHER_REC")) c->dither_rec = atoi(e) != 0;
     if (const char *e = getenv("SNES_DITHER4_MAX")) { int v = atoi(e); if (v >= 0) c->dither4_max = (uint32_t)v; }
+    if (const char *e = getenv("SNES_DOWN1_GRID")) { int v = atoi(e); if (v >= 64) c->sp.down1_grid = (uint32_t)v; }
     if (const char *e = getenv("SNES_VSPLIT")) c->sp.vsplit = atoi(e) != 0;
     if (const char *e = getenv("SNES_SCAN4_MAX")) { int v = atoi(e); if (v >= 0) c->sp.scan4_max = (uint32_t)v; }
     if (const char *e = getenv("SNES_H2Q_MAX")) { int v = atoi(e); if (v >= 0) c->sp.h2q_max = (uint32_t)v; }
