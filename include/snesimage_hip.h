@@ -105,8 +105,8 @@ int32_t snesimage_step_commit(snesimage_ctx *ctx, const double *d_errors);
  * (strict <, lib.rs:216-219), so a *window* scores the next K calls of the schedule against the current palette in one set
  * of launches, applies their decisions in order and stops behind the first call that changed the state; the calls behind
  * it are void and are scored again by the next window.  Bit-identical to snesimage_schedule_next + snesimage_step per
- * call, for every K.  Windows cover the group-sparse path (32 rows and more; with --dither, subpalettes of two entries and more); other configurations are stepped call
- * by call inside snesimage_run_slots. */
+ * call, for every K.  Windows cover the group-sparse path (every height since round 4; with --dither, subpalettes of two entries and more);
+ * what is left — one-entry subpalettes with --dither, a library run with SNES_SPARSE=0 — is stepped call by call inside snesimage_run_slots. */
 typedef struct { double error; int32_t best_k; uint8_t rgb5[3]; uint8_t changed; } snesimage_call_result; /* what snesimage_last_step reports after the call */
 typedef struct {
     uint32_t calls, accepted, windows, voided;   /* calls that took effect; calls that changed the palette; launch sets collected;

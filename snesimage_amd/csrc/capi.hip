@@ -585,7 +585,7 @@ int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si) {
         hipLaunchKernelGGL(k_build_plist, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, win_pack, (int)c->npx, sp.plist, sp.plist_count);
         SparseParams P = sparse_params(c, c->nlanes); // B has its own item list and counters
         P.is_base = 1; P.ncand = 1; P.k0 = P.base;
-        hipLaunchKernelGGL(k_base_down, dim3((unsigned)((G.W / 32) * (G.H / 32))), dim3(256), 0, c->stream, P); // B: every row of every scale
+        hipLaunchKernelGGL(k_base_down, dim3((unsigned)((G.W / 32) * ((G.H + 31) / 32))), dim3(256), 0, c->stream, P); // B: every row of every scale
         // B's H and V passes are long single-image sweeps (latency-bound); they run on their own stream beside the
         // candidates' scan / downscale / H pass, which only need B's linear-RGB rows.  The candidates' V pass waits for them.
         // (SNES_BASE_STREAM=0 keeps them on the context's stream: with many contexts on one device the extra streams only
@@ -921,7 +921,7 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     if (const char *e = getenv("SNES_CHUNK")) { int v = atoi(e); if (v > 0) c->chunk = (uint32_t)v; }
     if (const char *e = getenv("SNES_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->nlanes = (uint32_t)v; }
     // the group-sparse path covers the no-dither remap (RGB keys or CIEDE2000) and the RGB Floyd-Steinberg remap
-    c->sp.enabled = (h >= 32); // (B's downscale walks 32 x 32 blocks of pixels)
+    c->sp.enabled = true; // every height the library takes (8 .. 256 rows; until round 4: 32 and more — B's downscale, which walks 32 x 32 blocks of pixels, read past images of 8 and 16 rows)
     if (const char *e = getenv("SNES_SPARSE")) c->sp.enabled = c->sp.enabled && atoi(e) != 0;
     if (const char *e = getenv("SNES_BASE_STREAM")) c->sp.side = atoi(e) != 0;
     if (const char *e = getenv("SNES_LPT")) c->sp.lpt = atoi(e) != 0;

@@ -631,18 +631,21 @@ __device__ __forceinline__ void base_down_body(const SparseParams &P) {
     {
         const int lx = t & 15, ly = t >> 4;
         const int X1 = bx * 16 + lx, Y1 = by * 16 + ly;
+        const bool in1 = Y1 < G.sh[1]; // (images of 8 and 16 rows: a block of 32 x 32 pixels reaches below the image)
         float sum[3] = {0.0f, 0.0f, 0.0f};
+        if (in1) {
 #pragma unroll
-        for (int iy = 0; iy < 2; iy++)
+            for (int iy = 0; iy < 2; iy++)
 #pragma unroll
-            for (int ix = 0; ix < 2; ix++) {
-                const uint32_t lo = (uint32_t)P.pack[(size_t)(Y1 * 2 + iy) * G.W + X1 * 2 + ix];
-                const uint32_t ci = P.use_maps ? maps_ci(P, P.bmap, true, X1 * 2 + ix, Y1 * 2 + iy, lo) : lo >> 24;
-                sum[0] += s_lin[3 * ci]; sum[1] += s_lin[3 * ci + 1]; sum[2] += s_lin[3 * ci + 2];
-            }
+                for (int ix = 0; ix < 2; ix++) {
+                    const uint32_t lo = (uint32_t)P.pack[(size_t)(Y1 * 2 + iy) * G.W + X1 * 2 + ix];
+                    const uint32_t ci = P.use_maps ? maps_ci(P, P.bmap, true, X1 * 2 + ix, Y1 * 2 + iy, lo) : lo >> 24;
+                    sum[0] += s_lin[3 * ci]; sum[1] += s_lin[3 * ci + 1]; sum[2] += s_lin[3 * ci + 2];
+                }
+        }
         const float v[3] = {sum[0] * 0.25f, sum[1] * 0.25f, sum[2] * 0.25f};
         l1[0][ly][lx] = v[0]; l1[1][ly][lx] = v[1]; l1[2][ly][lx] = v[2];
-        base_store(P, mine, 1, X1, Y1, v, G.nscales > 2);
+        if (in1) base_store(P, mine, 1, X1, Y1, v, G.nscales > 2);
     }
     __syncthreads();
 #define SNES_BASE_LEVEL(S, SRC, DST, DIM)                                                              \
@@ -656,7 +659,7 @@ __device__ __forceinline__ void base_down_body(const SparseParams &P) {
                 sum += SRC[c][2 * ly + 1][2 * lx]; sum += SRC[c][2 * ly + 1][2 * lx + 1];              \
                 v[c] = sum * 0.25f; DST[c][ly][lx] = v[c];                                             \
             }                                                                                          \
-            base_store(P, mine, S, bx * DIM + lx, by * DIM + ly, v, G.nscales > S + 1);                \
+            if (by * DIM + ly < G.sh[S]) base_store(P, mine, S, bx * DIM + lx, by * DIM + ly, v, G.nscales > S + 1); \
         }                                                                                              \
         __syncthreads();                                                                               \
     }
@@ -666,7 +669,7 @@ __device__ __forceinline__ void base_down_body(const SparseParams &P) {
     if (G.nscales > 5 && t == 0) {
         float v[3];
         for (int c = 0; c < 3; c++) { float sum = 0.0f; sum += l4[c][0][0]; sum += l4[c][0][1]; sum += l4[c][1][0]; sum += l4[c][1][1]; v[c] = sum * 0.25f; }
-        base_store(P, mine, 5, bx, by, v, false);
+        if (by < G.sh[5]) base_store(P, mine, 5, bx, by, v, false);
     }
 #undef SNES_BASE_LEVEL
 }

@@ -973,12 +973,13 @@ def test_edge_map_product_form_stays_within_bounds_on_adversarial_inputs(S, O):
     g.close()
 
 
-@pytest.mark.parametrize("h", [32, 64, 128])
+@pytest.mark.parametrize("h", [8, 16, 32, 64, 128])
 @pytest.mark.parametrize("flags", [{}, {"dither": True}, {"perceptual": True}], ids=["rgb", "dither", "perceptual"])
 def test_small_heights_sparse_path_equals_dense_path(S, O, h, flags, monkeypatch):
-    """Heights below 256 (down to 32 rows: B's downscale walks 32 x 32 blocks) on the group-sparse path: the narrowest
-    scales are a single 4-row group there.  Against the dense path bit for bit, a handful against the oracle, and the slot
-    windows against call-by-call stepping."""
+    """Heights below 256 on the group-sparse path, down to the library's smallest (8 rows: two 4-row groups, two scales;
+    round 4 — until then B's downscale, which walks 32 x 32 blocks of pixels, kept 8 and 16 rows on the dense path): the
+    narrowest scales are a single 4-row group there.  Against the dense path bit for bit, a handful against the oracle, and
+    the slot windows against call-by-call stepping."""
     from snesimage_amd.synth import synth_image
     img = synth_image(0x5EED0020 + h, 256, h, 1 if h == 64 else 0)
     monkeypatch.setenv("SNES_SPARSE", "0")

@@ -47,15 +47,43 @@ def test_concurrent_images_equal_one_at_a_time(batched, flags):
 
 @pytest.mark.gpu
 def test_batch_rejects_what_it_does_not_cover():
-    """The batched launches cover the group-sparse path: images of 8 or 16 rows (dense path) are refused, not mis-stepped."""
+    """The batched launches cover the group-sparse path.  Round 4: that is every height (16-row images, refused until then, now
+    step like their solo twins); what is left — --dither with one-entry subpalettes — is refused, not mis-stepped."""
+    import ctypes as C
+    import numpy as np
     import snesimage_amd as S
+    from snesimage_amd import _ffi
     from snesimage_amd.synth import synth_image
     from snesimage_amd.throughput import IMAGE_SEED0, ImageBatch
-    b = ImageBatch(((i, synth_image(IMAGE_SEED0 + i, 256, 16)) for i in (1, 2)), 2, 3, candidates=8, batched=True)
-    with pytest.raises(S.SnesImageError) as e:
-        b.initialize()
-    assert e.value.code == -5
+    imgs = [(i, synth_image(IMAGE_SEED0 + i, 256, 16)) for i in (1, 2)]
+    b = ImageBatch(iter(imgs), 2, 3, candidates=8, batched=True)
+    b.initialize()
+    solo = [S.OptimizedImage(im, 2, 3) for _, im in imgs]
+    for z, m in zip(solo, b.images):
+        z.tile_palettes, z.palette = m.tile_palettes, m.palette
+        z.optimize()
+    b.run(5)
+    sched = S.schedule(2, 3, 5)
+    for (gid, _), z, m in zip(imgs, solo, b.images):
+        for j, (method, p, idx, ch, _) in enumerate(sched):
+            z.step(method, p, idx, ch, 1 + gid, j, 8)  # (ImageBatch.run: candidate streams keyed (1 + image index, call number))
+        assert np.array_equal(z.palette, m.palette) and np.array_equal(z.palette_map, m.palette_map) and z.error() == m.error()
     b.close()
+    for z in solo:
+        z.close()
+    L = _ffi.load()
+    ctxs = []
+    for _, im in imgs:
+        g = S.OptimizedImage(synth_image(IMAGE_SEED0, 256, 64), 4, 1, dither=True)
+        g.tile_palettes = (np.arange(1024) % 4).astype(np.uint8)
+        g.palette = np.array([[3, 5, 7], [20, 11, 2], [9, 30, 14], [28, 27, 25]], np.uint8)
+        g.optimize()
+        ctxs.append(g)
+    arr = (C.c_void_p * 2)(*[g._c for g in ctxs])
+    out = C.c_void_p()
+    assert L.snesimage_batch_create(arr, 2, C.byref(out)) == -5, L.snesimage_last_error()
+    for g in ctxs:
+        g.close()
 
 
 @pytest.mark.gpu
