@@ -441,12 +441,12 @@ def main():
         per_launch = tim["candidates"] / max(1, tim["launches"])
         achieved = ALGO_BYTES_PER_CANDIDATE * per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # Counters cannot be collected from inside the benchmark: HBM bytes and VALU instructions of the dominant kernel come
-        # from the committed rocprofv3 PMC passes of this configuration (profiles/r2_pmc_<config>.json, one pass per counter
+        # from the committed rocprofv3 PMC passes of this configuration (profiles/r4_pmc_<config>.json, one pass per counter
         # set; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE), scaled from that run's
         # candidates per launch to this run's.  null where no measurement of the kernel is committed.
         traffic, traffic_src, valu, stale_pmc = None, None, None, None
         try:
-            pmc_path = os.path.join("profiles", "r3_pmc_%s.json" % args.config)
+            pmc_path = os.path.join("profiles", "r4_pmc_%s.json" % args.config)
             if not os.path.exists(os.path.join(ROOT, pmc_path)):
                 stale_pmc = "no counter summary %s: traffic and valu_roofline withheld" % pmc_path
             pmc = json.load(open(os.path.join(ROOT, pmc_path)))
