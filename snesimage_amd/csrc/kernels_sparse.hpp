@@ -41,6 +41,11 @@ struct CandMeta {
     short gslot[kGroupsTotal];             // per scale: group -> slot, -1 if unchanged
     unsigned char gcb[kGroupsTotal];       // per scale: group -> first 64-column block holding a won pixel (0 at scales narrower than 64)
 };
+// a work item: candidate (storage index), 4-row group of the scale, the group's slot in the candidate's storage, channel
+__device__ __forceinline__ int item_k(unsigned int it) { return (int)(it >> 14); }
+__device__ __forceinline__ int item_g(unsigned int it) { return (int)((it >> 8) & 63u); }
+__device__ __forceinline__ int item_j(unsigned int it) { return (int)((it >> 2) & 63u); }
+__device__ __forceinline__ int item_ch(unsigned int it) { return (int)(it & 3u); }
 constexpr int kColBuckets = 4; // 64-column blocks of the widest scale: work items are listed per (scale, first block)
 constexpr int kItemLists = kMaxScales * kColBuckets;
 
@@ -63,7 +68,7 @@ struct SparseParams {
     int perceptual; const float *labpx, *cand_lab; uint32_t *bitmap;
     const float *img1C4, *mu1R4, *sd1R4, *a1R4; const double *r1R4; // source arrays in the blocked layouts, + G.src_off[s] (maps_accumulate)
     float *store; CandMeta *meta;
-    unsigned int *items; int *item_count; long long item_stride; // per (scale, first column block b): items[(s*4+b)*item_stride + i] = cand*256 + slot*4 + ch
+    unsigned int *items; int *item_count; long long item_stride; // per (scale, first column block b): items[(s*4+b)*item_stride + i] = cand << 14 | group << 8 | slot << 2 | ch (item_k / item_g / item_j / item_ch)
     float *ckf; double *cka; double *part; float *ckh;
     const float *zeros; // 3 * 4 * W floats of 0.0f: what sparse_v2_body prefetches for the group below the image
     float *trash;       // 256 floats nobody reads: where the H pass's flush sends the stores of lanes that have nothing to store (its store instructions carry no predicate)
@@ -174,7 +179,7 @@ __device__ __forceinline__ void scan_publish(const SparseParams &P, const int k,
             const unsigned long long mb = __ballot(mine);
             if (mine) {
                 unsigned int *dst = P.items + (size_t)(s * kColBuckets + b) * P.item_stride + s_off[w][s * kColBuckets + b] + 3 * __popcll(mb & below_mask);
-                const unsigned int v = (unsigned int)k * 256u + (unsigned int)below * 4u;
+                const unsigned int v = ((unsigned int)k << 14) | ((unsigned int)lane << 8) | ((unsigned int)below << 2); // (lane = the group: its number rides along, so that the consumers need no second look-up)
                 dst[0] = v; dst[1] = v + 1u; dst[2] = v + 2u;
             }
         }
@@ -560,16 +565,25 @@ __device__ __forceinline__ void sparse_down1_body(const SparseParams &P, const i
 #pragma unroll
     for (int b = 0; b < kColBuckets; b++) { cnt[b] = b < nb ? P.item_count[kColBuckets + b] / 3 : 0; total += cnt[b]; }
     __syncthreads();
-    for (int gi = bx; gi < total; gi += gx) {
+    // A group is two pixels per thread behind a chain of look-ups (item -> candidate's colour): the block fetches the NEXT
+    // group's item and colour while it works on this one (the item carries the group's number: no look-up in the candidate's lists)
+    auto fetch_item = [&](int gi) -> unsigned int {
         int b = 0, li = gi;
         while (li >= cnt[b]) { li -= cnt[b]; b++; }
-        const unsigned int it = P.items[(size_t)(kColBuckets + b) * P.item_stride + 3 * (size_t)li]; // channel 0's item of the group
-        const int k = (int)(it >> 8), j = (int)((it >> 2) & 63u);
-        const CandMeta *M = P.meta + k;
-        const int g = M->glist[P.S.goff[1] + j];
+        return P.items[(size_t)(kColBuckets + b) * P.item_stride + 3 * (size_t)li]; // channel 0's item of the group
+    };
+    unsigned int it_n = bx < total ? fetch_item(bx) : 0u;
+    uint32_t crgb_n = 0u; float cl_n[3] = {0.0f, 0.0f, 0.0f};
+    if (bx < total) { const float *ct = P.cand_tab + 8 * (size_t)item_k(it_n); crgb_n = __float_as_uint(ct[6]); cl_n[0] = ct[0]; cl_n[1] = ct[1]; cl_n[2] = ct[2]; }
+    for (int gi = bx; gi < total; gi += gx) {
+        const unsigned int it = it_n;
+        const uint32_t crgb = crgb_n; const float cl0 = cl_n[0], cl1 = cl_n[1], cl2 = cl_n[2];
+        if (gi + gx < total) {
+            it_n = fetch_item(gi + gx);
+            const float *ct = P.cand_tab + 8 * (size_t)item_k(it_n); crgb_n = __float_as_uint(ct[6]); cl_n[0] = ct[0]; cl_n[1] = ct[1]; cl_n[2] = ct[2];
+        }
+        const int k = item_k(it), j = item_j(it), g = item_g(it);
         float *mine = P.store + (size_t)k * P.S.cand_stride;
-        const uint32_t crgb = __float_as_uint(P.cand_tab[8 * (size_t)k + 6]);
-        const float cl0 = P.cand_tab[8 * (size_t)k], cl1 = P.cand_tab[8 * (size_t)k + 1], cl2 = P.cand_tab[8 * (size_t)k + 2];
         float *ol = mine + P.S.off_lin[1] + (size_t)j * 12 * Ws;
         float *oc = mine + P.S.off_xybC[1] + (size_t)j * 12 * Ws, *orr = mine + P.S.off_xybR[1] + (size_t)j * 12 * Ws;
         for (int rem = t; rem < 4 * Ws; rem += 256) {
@@ -710,12 +724,11 @@ __device__ __forceinline__ void sparse_h_body(const SparseParams &P) {
     const int qi = i0 + (lane >> 2);
     const bool valid = qi < count;
     const unsigned int it = P.items[(size_t)list * P.item_stride + (valid ? qi : i0)];
-    const int k = (int)(it >> 8), j = (int)((it >> 2) & 63u), ch = (int)(it & 3u);
+    const int k = item_k(it), j = item_j(it), ch = item_ch(it);
     const bool is_base = (k == P.base);
-    const CandMeta *M = P.meta + k;
     const int W = G.sw[s], H = G.sh[s];
     const int r = lane & 3;
-    const int y = 4 * (int)M->glist[P.S.goff[s] + j] + r;
+    const int y = 4 * item_g(it) + r;
     const size_t ns = (size_t)W * H;
     const float cand_v = is_base ? 0.0f : P.cand_tab[8 * (size_t)k + 3 + ch];
     const uint32_t crgb = is_base ? 0u : __float_as_uint(P.cand_tab[8 * (size_t)k + 6]);

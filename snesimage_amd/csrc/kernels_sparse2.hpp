@@ -123,9 +123,8 @@ __device__ __forceinline__ void sparse_h2_body(const SparseParams &P, const int 
         const int qi = i0 + (lane >> 2);
         const bool valid = qi < count;
         const unsigned int it = P.items[(size_t)list * P.item_stride + (valid ? qi : i0)];
-        const int k = (int)(it >> 8), j = (int)((it >> 2) & 63u), ch = (int)(it & 3u);
-        const CandMeta *M = P.meta + k;
-        const int y = 4 * (int)M->glist[P.S.goff[s] + j] + r;
+        const int k = item_k(it), j = item_j(it), ch = item_ch(it);
+        const int y = 4 * item_g(it) + r;
         const size_t ns = (size_t)W * H;
         const float cand_v = (S0 && !BASE) ? P.cand_tab[8 * (size_t)k + 3 + ch] : 0.0f;
         const uint32_t crgb = (S0 && !BASE) ? __float_as_uint(P.cand_tab[8 * (size_t)k + 6]) : 0u;
@@ -283,9 +282,8 @@ __device__ __forceinline__ void sparse_h2q_body(const SparseParams &P, const int
         const int qi = i0 + im;
         const bool valid = qi < count;
         const unsigned int it = P.items[(size_t)list * P.item_stride + (valid ? qi : i0)];
-        const int k = (int)(it >> 8), j = (int)((it >> 2) & 63u), ch = (int)(it & 3u);
-        const CandMeta *M = P.meta + k;
-        const int y = 4 * (int)M->glist[P.S.goff[s] + j] + r;
+        const int k = item_k(it), j = item_j(it), ch = item_ch(it);
+        const int y = 4 * item_g(it) + r;
         const size_t ns = (size_t)W * H;
         const float cand_v = (S0 && !BASE) ? P.cand_tab[8 * (size_t)k + 3 + ch] : 0.0f;
         const uint32_t crgb = (S0 && !BASE) ? __float_as_uint(P.cand_tab[8 * (size_t)k + 6]) : 0u;
