@@ -87,6 +87,12 @@ __global__ __launch_bounds__(64) void kb_sparse_h2q(const BatchArgs *__restrict_
 __global__ __launch_bounds__(64) void kb_sparse_h2q_base(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_h2q_dispatch<true>(a.Pb, bb.y, bb.x, (int)gridDim.x); }
 __global__ __launch_bounds__(256, 5) void kb_sparse_v2(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; if (bb.y < a.Pc.G.nscales && a.Pc.G.sw[bb.y] >= 64) sparse_v2_body<false>(a.Pc, bb.y, bb.x); }
 __global__ __launch_bounds__(256) void kb_sparse_v_base(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; if (bb.y < a.Pb.G.nscales && a.Pb.G.sw[bb.y] >= 64) sparse_v2_body<true>(a.Pb, bb.y, bb.x); }
+// B's wide V sweep on two waves per 64 columns (sparse_v2_base_split_body): grid.x = column block, grid.y = channel + 3 * scale, grid.z = member
+__global__ __launch_bounds__(128) void kb_sparse_v_base_split(const BatchArgs *__restrict__ A, const int *__restrict__ dead) {
+    SNES_BATCH_IMG;
+    const int s = (int)blockIdx.y / 3, ch = (int)blockIdx.y - 3 * s;
+    if (s < a.Pb.G.nscales && a.Pb.G.sw[s] >= 64 && (int)blockIdx.x < (a.Pb.G.sw[s] >> 6)) sparse_v2_base_split_body(a.Pb, s, ch, (int)blockIdx.x);
+}
 __global__ __launch_bounds__(256, 1) void kb_sparse_v_base_narrow(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_v_base_narrow_dispatch(a.Pb); }
 __global__ __launch_bounds__(1024) void kb_sparse_order(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_order_body(a.Pc, const_cast<int *>(a.Pc.order)); }
 __global__ __launch_bounds__(256, 2) void kb_sparse_v(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_v_body<false, 2, 2>(a.Pc, (int)blockIdx.y + a.Pc.s_first); }
