@@ -241,6 +241,8 @@ def main():
     # collective goes through gloo): SNES_BENCH_SHARE_GPU=1 puts every rank on device 0, SNES_BENCH_BACKEND=gloo replaces RCCL
     if os.environ.get("SNES_BENCH_SHARE_GPU") == "1":
         local_rank = 0
+        # (the ranks' slot contexts — 0.43 GB per call of a window, two sets — have to fit ONE device's HBM side by side)
+        os.environ.setdefault("SNES_WINDOW_MAX", str(max(8, 64 // max(1, world))))
     backend = os.environ.get("SNES_BENCH_BACKEND", "nccl")
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d inside a %d-rank launcher environment" % (args.gpus, world))
