@@ -151,6 +151,8 @@ struct snesimage_ctx {
         bool down1 = true; // scale 1 of the candidates' downscale in a kernel of its own, one block per changed group (SNES_DOWN1=0: inside k_sparse_down)
         bool counters_cleared = false; // k_prep cleared B's counters for the current pack
         uint32_t h2q_max = 512; // longest list that takes k_sparse_h2q (SNES_H2Q_MAX; 0 = never)
+        bool down_tiles = true; // scales 2.. of the candidates' downscale one block per changed group of scale 3 (SNES_DOWN_TILES=0: k_sparse_down, one block per candidate, scale after scale)
+        uint32_t tiles_grid = 4096; // most blocks of k_sparse_down_tiles (SNES_TILES_GRID)
         uint32_t down1_grid = 32768; // most blocks of k_sparse_down1 (SNES_DOWN1_GRID)
         bool vsplit = true; // B's wide V sweep with recurrences and maps on two waves (k_sparse_v2_base_split; SNES_VSPLIT=0: one wave does both)
         uint32_t scan4_max = 2048; // longest list whose scan deals a candidate's contested pixels to four waves (SNES_SCAN4_MAX; 0 = never)
@@ -677,6 +679,10 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     if (sp.down1 && G.nscales > 2) { // scale 1 one block per changed group (the scan's item lists name them), then the scales that do depend on each other
         size_t gd = (size_t)nc * 8; if (gd > sp.down1_grid) gd = sp.down1_grid; // (~6 changed groups per candidate; grid-stride beyond)
         hipLaunchKernelGGL(k_sparse_down1, dim3((unsigned)gd), dim3(256), 0, stream, P);
+        if (sp.down_tiles && G.nscales >= 4) { // scales 2..: one block per changed group of scale 3
+            size_t gt = ((size_t)nc * (G.sh[3] / 4) + SNES_DOWN_TILES_U - 1) / SNES_DOWN_TILES_U; if (gt > sp.tiles_grid) gt = sp.tiles_grid; // (4-5 of a candidate's 8 groups change; the block takes SNES_DOWN_TILES_U at a time, grid-stride beyond)
+            hipLaunchKernelGGL(k_sparse_down_tiles, dim3((unsigned)gt), dim3(512), 0, stream, P);
+        } else
         hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P, -2);
     } else hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P, 0);
     if (sp.side) HIPCHK(hipStreamWaitEvent(stream, sp.ev_base_h, 0)); // B's H-pass checkpoints (a short list gets here before B's sweep is through)
@@ -933,6 +939,8 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     if (const char *e = getenv("SNES_DITHER4_MAX")) { int v = atoi(e); if (v >= 0) c->dither4_max = (uint32_t)v; }
     if (const char *e = getenv("SNES_DOWN1_GRID")) { int v = atoi(e); if (v >= 64) c->sp.down1_grid = (uint32_t)v; }
     if (const char *e = getenv("SNES_VSPLIT")) c->sp.vsplit = atoi(e) != 0;
+    if (const char *e = getenv("SNES_DOWN_TILES")) c->sp.down_tiles = atoi(e) != 0;
+    if (const char *e = getenv("SNES_TILES_GRID")) { int v = atoi(e); if (v >= 64) c->sp.tiles_grid = (uint32_t)v; }
     if (const char *e = getenv("SNES_SCAN4_MAX")) { int v = atoi(e); if (v >= 0) c->sp.scan4_max = (uint32_t)v; }
     if (const char *e = getenv("SNES_H2Q_MAX")) { int v = atoi(e); if (v >= 0) c->sp.h2q_max = (uint32_t)v; }
     if (const char *e = getenv("SNES_HGRID")) { int v = atoi(e); if (v >= 1) c->sp.hgrid = (uint32_t)v; }

@@ -476,6 +476,9 @@ __device__ __forceinline__ void dither_diff_body(const SparseParams &P) {
 // ---- downscale chain + XYB on changed groups only -------------------------------------------------------
 // base: grid.x blocks share the rows of each scale (launched once per scale, P.ncand = scale to do);
 // candidates: one block per candidate walks the scales itself.
+#ifndef SNES_DOWN_TILES_U
+#define SNES_DOWN_TILES_U 2
+#endif
 __device__ __forceinline__ void sparse_down_body(const SparseParams &P, int only_scale, const int bx) { // bx: blockIdx.x unless the caller remaps blocks
     __shared__ float s_lin[256 * 3];
     const Geom &G = P.G;
@@ -611,6 +614,187 @@ __device__ __forceinline__ void sparse_down1_body(const SparseParams &P, const i
                 ol[(size_t)c * 4 * Ws + (size_t)(x >> 2) * 16 + r * 4 + (x & 3)] = v[c];
                 oc[(size_t)c * 4 * Ws + (size_t)(x >> 2) * 16 + r * 4 + (x & 3)] = xyb[c];
                 if (Ws < 64) orr[(size_t)c * 4 * Ws + (size_t)x * 4 + r] = xyb[c];
+            }
+        }
+    }
+}
+
+// ---- scales 2.. of the candidates' downscale, one block per changed group of scale 3 --------------------------------------
+// sparse_down_body walks a candidate's scales one after the other: every scale reads the linear planes the one before stored,
+// behind a block barrier — four dependent trips to memory for a few thousand pixels.  Here a block of eight waves takes
+// one (candidate, changed group of scale 3): the group's four rows are eight rows of scale 2 — 8 x 64 pixels, one 8 x 8 tile
+// per wave, one pixel per lane, averaged from scale 1 (the candidate's own linear planes where that group changed, B's where
+// not; an unchanged group of scale 2 recomputed from B's scale 1 has the very bits B stored) — and scale 3 follows by
+// shuffles inside the tile, scales 4 and 5 from the 4 x 32 pixels of scale 3 in LDS: one trip to memory, one barrier.  The
+// sums run in sparse_down_body's order ((a + b) + c) + d over rows 2y, 2y+1 and columns 2x, 2x+1.
+// A changed group of scale 4 (5) spans two (four) groups of scale 3, not all of them changed: the rows under an unchanged
+// one are B's, copied into the candidate's slot by the block of the group's changed neighbour (scale 5: the first changed one).
+// The candidates' linear planes of scales 2.. are read by nobody and not stored.
+// Needs G.nscales >= 4 (a scale 3) and W = 256 (scale 2 is 64 wide: eight tiles; scales 3.. are narrow: both layouts stored).
+// A group is three dependent trips to memory (item -> the candidate's group tables -> the planes of scale 1) for half a
+// microsecond of arithmetic, with the CU's wave slots full: a block takes U groups at a time, every trip made for all of
+// them before the first is used.
+template <int U>
+__device__ __forceinline__ void sparse_down_tiles_body(const SparseParams &P, const int bx, const int gx) {
+    __shared__ float s_v3[U][3][4][32];
+    const Geom &G = P.G;
+    const int t = threadIdx.x, lane = t & 63, tx = t >> 6;
+    const int ly = lane >> 3, lx = lane & 7;
+    const int total = P.item_count[3 * kColBuckets] / 3;
+    const int NG3 = G.sh[3] >> 2;
+    const float *basep = P.store + (size_t)P.base * P.S.cand_stride;
+    const unsigned int *items = P.items + (size_t)(3 * kColBuckets) * P.item_stride;
+    const int Wp = G.sw[1], W2 = G.sw[2];
+    for (int g0 = bx * U; g0 < total; g0 += gx * U) {
+        unsigned int it[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) it[u] = items[3 * (size_t)min(g0 + u, total - 1)]; // (past the list: the last group once more, nothing stored)
+        short sl[U], sl2[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const CandMeta *M = P.meta + item_k(it[u]);
+            const int y2 = 8 * item_g(it[u]) + ly;
+            sl[u] = M->gslot[P.S.goff[1] + (y2 >> 1)];
+            sl2[u] = M->gslot[P.S.goff[2] + (y2 >> 2)];
+        }
+        // ---- scale 2: pixel (8 ty + ly, 8 tx + lx) from rows 2y, 2y+1 of scale 1 (one group: 4 ty + ly / 2) ----
+        float2 a[U][3], b[U][3];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const float *mine = P.store + (size_t)item_k(it[u]) * P.S.cand_stride;
+            const int gp = (8 * item_g(it[u]) + ly) >> 1, rp = (ly & 1) * 2, x2 = 8 * tx + lx;
+            const float *grp = sl[u] >= 0 ? mine + P.S.off_lin[1] + (size_t)sl[u] * 12 * Wp : basep + P.S.off_lin[1] + (size_t)gp * 12 * Wp;
+            const float *q0 = grp + (size_t)((2 * x2) >> 2) * 16 + rp * 4 + ((2 * x2) & 3);
+#pragma unroll
+            for (int c = 0; c < 3; c++) { a[u][c] = *reinterpret_cast<const float2 *>(q0 + (size_t)c * 4 * Wp); b[u][c] = *reinterpret_cast<const float2 *>(q0 + (size_t)c * 4 * Wp + 4); }
+        }
+        __syncthreads(); // (the block's last read of s_v3 for the groups before)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool live = g0 + u < total;
+            float *mine = P.store + (size_t)item_k(it[u]) * P.S.cand_stride;
+            const int y2 = 8 * item_g(it[u]) + ly, x2 = 8 * tx + lx;
+            float v2[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float sum = 0.0f;
+                sum += a[u][c].x; sum += a[u][c].y; sum += b[u][c].x; sum += b[u][c].y;
+                v2[c] = sum * 0.25f;
+            }
+            if (live && sl2[u] >= 0) { // (uniform over each half of the wave: rows 0-3 and 4-7 of the tile are the two groups of scale 2)
+                float X, Y, B;
+                linear_to_positive_xyb(v2[0], v2[1], v2[2], X, Y, B);
+                float *oc = mine + P.S.off_xybC[2] + (size_t)sl2[u] * 12 * W2 + (size_t)(x2 >> 2) * 16 + (y2 & 3) * 4 + (x2 & 3);
+                oc[0] = X; oc[(size_t)4 * W2] = Y; oc[(size_t)8 * W2] = B;
+            }
+            // scale 3 inside the tile: the lanes of even row and column hold pixel (4 ty + ly / 2, 4 tx + lx / 2)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float b1 = __shfl(v2[c], (lane + 1) & 63), c1 = __shfl(v2[c], (lane + 8) & 63), d1 = __shfl(v2[c], (lane + 9) & 63);
+                float sum = 0.0f;
+                sum += v2[c]; sum += b1; sum += c1; sum += d1;
+                if (((ly | lx) & 1) == 0) s_v3[u][c][ly >> 1][4 * tx + (lx >> 1)] = sum * 0.25f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (g0 + u >= total) break;
+            const int k = item_k(it[u]), ty = item_g(it[u]), j3 = item_j(it[u]);
+            const CandMeta *M = P.meta + k;
+            float *mine = P.store + (size_t)k * P.S.cand_stride;
+            const float (*v3)[4][32] = s_v3[u];
+            if (t < 128) { // scale 3: 4 rows x 32 pixels
+                const int r = t >> 5, x = t & 31, Ws = G.sw[3];
+                float X, Y, B;
+                linear_to_positive_xyb(v3[0][r][x], v3[1][r][x], v3[2][r][x], X, Y, B);
+                float *oc = mine + P.S.off_xybC[3] + (size_t)j3 * 12 * Ws + (size_t)(x >> 2) * 16 + r * 4 + (x & 3);
+                float *orr = mine + P.S.off_xybR[3] + (size_t)j3 * 12 * Ws + (size_t)x * 4 + r;
+                oc[0] = X; oc[(size_t)4 * Ws] = Y; oc[(size_t)8 * Ws] = B;
+                orr[0] = X; orr[(size_t)4 * Ws] = Y; orr[(size_t)8 * Ws] = B;
+            } else if (t < 192) { // scale 4: rows 2 ty, 2 ty + 1 x 16 pixels
+                const int i = t - 128;
+                if (G.nscales > 4 && i < 32) {
+                    const int a4 = i >> 4, x = i & 15, Ws = G.sw[4];
+                    const int y4 = 2 * ty + a4, r = y4 & 3;
+                    const int j4 = M->gslot[P.S.goff[4] + (y4 >> 2)];
+                    float v[3];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        float sum = 0.0f;
+                        sum += v3[c][2 * a4][2 * x]; sum += v3[c][2 * a4][2 * x + 1]; sum += v3[c][2 * a4 + 1][2 * x]; sum += v3[c][2 * a4 + 1][2 * x + 1];
+                        v[c] = sum * 0.25f;
+                    }
+                    float X, Y, B;
+                    linear_to_positive_xyb(v[0], v[1], v[2], X, Y, B);
+                    float *oc = mine + P.S.off_xybC[4] + (size_t)j4 * 12 * Ws + (size_t)(x >> 2) * 16 + r * 4 + (x & 3);
+                    float *orr = mine + P.S.off_xybR[4] + (size_t)j4 * 12 * Ws + (size_t)x * 4 + r;
+                    oc[0] = X; oc[(size_t)4 * Ws] = Y; oc[(size_t)8 * Ws] = B;
+                    orr[0] = X; orr[(size_t)4 * Ws] = Y; orr[(size_t)8 * Ws] = B;
+                }
+            } else if (t < 256) { // scale 5: row ty x 8 pixels
+                const int x = t - 192;
+                if (G.nscales > 5 && x < 8) {
+                    const int Ws = G.sw[5], r = ty & 3;
+                    const int j5 = M->gslot[P.S.goff[5] + (ty >> 2)];
+                    float v[3];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        float v4[2][2];
+#pragma unroll
+                        for (int a4 = 0; a4 < 2; a4++)
+#pragma unroll
+                            for (int e = 0; e < 2; e++) {
+                                const int x4 = 2 * x + e;
+                                float sum = 0.0f;
+                                sum += v3[c][2 * a4][2 * x4]; sum += v3[c][2 * a4][2 * x4 + 1]; sum += v3[c][2 * a4 + 1][2 * x4]; sum += v3[c][2 * a4 + 1][2 * x4 + 1];
+                                v4[a4][e] = sum * 0.25f;
+                            }
+                        float sum = 0.0f;
+                        sum += v4[0][0]; sum += v4[0][1]; sum += v4[1][0]; sum += v4[1][1];
+                        v[c] = sum * 0.25f;
+                    }
+                    float X, Y, B;
+                    linear_to_positive_xyb(v[0], v[1], v[2], X, Y, B);
+                    float *oc = mine + P.S.off_xybC[5] + (size_t)j5 * 12 * Ws + (size_t)(x >> 2) * 16 + r * 4 + (x & 3);
+                    float *orr = mine + P.S.off_xybR[5] + (size_t)j5 * 12 * Ws + (size_t)x * 4 + r;
+                    oc[0] = X; oc[(size_t)4 * Ws] = Y; oc[(size_t)8 * Ws] = B;
+                    orr[0] = X; orr[(size_t)4 * Ws] = Y; orr[(size_t)8 * Ws] = B;
+                }
+            } else if (t < 320) { // scale 4: the two rows under the unchanged other half of the group are B's
+                const int sib = ty ^ 1;
+                if (G.nscales > 4 && sib < NG3 && M->gslot[P.S.goff[3] + sib] < 0) {
+                    const int Ws = G.sw[4], g4 = ty >> 1;
+                    const int j4 = M->gslot[P.S.goff[4] + g4];
+                    const float *bc = basep + P.S.off_xybC[4] + (size_t)g4 * 12 * Ws, *br = basep + P.S.off_xybR[4] + (size_t)g4 * 12 * Ws;
+                    float *oc = mine + P.S.off_xybC[4] + (size_t)j4 * 12 * Ws, *orr = mine + P.S.off_xybR[4] + (size_t)j4 * 12 * Ws;
+                    for (int i = t - 256; i < 3 * 2 * Ws; i += 64) { // (channel, row of the pair, column)
+                        const int c = i / (2 * Ws), rem = i % (2 * Ws), r = ((2 * sib) & 3) + rem / Ws, x = rem % Ws;
+                        const size_t ic = (size_t)c * 4 * Ws + (size_t)(x >> 2) * 16 + r * 4 + (x & 3), ir = (size_t)c * 4 * Ws + (size_t)x * 4 + r;
+                        oc[ic] = bc[ic]; orr[ir] = br[ir];
+                    }
+                }
+            } else if (t < 384) { // scale 5: the group's first changed group of scale 3 brings B's rows under the unchanged ones
+                if (G.nscales > 5) {
+                    const int g5 = ty >> 2, lo = 4 * g5, hi = min(lo + 4, NG3);
+                    bool first = true;
+                    for (int q = lo; q < ty; q++) first = first && M->gslot[P.S.goff[3] + q] < 0;
+                    if (first) {
+                        const int Ws = G.sw[5];
+                        const int j5 = M->gslot[P.S.goff[5] + g5];
+                        const float *bc = basep + P.S.off_xybC[5] + (size_t)g5 * 12 * Ws, *br = basep + P.S.off_xybR[5] + (size_t)g5 * 12 * Ws;
+                        float *oc = mine + P.S.off_xybC[5] + (size_t)j5 * 12 * Ws, *orr = mine + P.S.off_xybR[5] + (size_t)j5 * 12 * Ws;
+                        for (int q = lo; q < hi; q++) {
+                            if (q == ty || M->gslot[P.S.goff[3] + q] >= 0) continue;
+                            const int r = q & 3;
+                            for (int i = t - 320; i < 3 * Ws; i += 64) {
+                                const int c = i / Ws, x = i % Ws;
+                                const size_t ic = (size_t)c * 4 * Ws + (size_t)(x >> 2) * 16 + r * 4 + (x & 3), ir = (size_t)c * 4 * Ws + (size_t)x * 4 + r;
+                                oc[ic] = bc[ic]; orr[ir] = br[ir];
+                            }
+                        }
+                    }
+                }
             }
         }
     }
@@ -1172,6 +1356,7 @@ __global__ __launch_bounds__(256) void k_dither_first_lab(SparseParams P) { dith
 __global__ __launch_bounds__(1024) void k_dither_diff(SparseParams P) { dither_diff_body(P); }
 __global__ __launch_bounds__(256) void k_sparse_down(SparseParams P, int only_scale) { sparse_down_body(P, only_scale, (int)blockIdx.x); }
 __global__ __launch_bounds__(256) void k_sparse_down1(SparseParams P) { sparse_down1_body(P, (int)blockIdx.x, (int)gridDim.x); }
+__global__ __launch_bounds__(512) void k_sparse_down_tiles(SparseParams P) { sparse_down_tiles_body<SNES_DOWN_TILES_U>(P, (int)blockIdx.x, (int)gridDim.x); }
 __global__ __launch_bounds__(256) void k_base_down(SparseParams P) { base_down_body(P); }
 __global__ __launch_bounds__(64) void k_sparse_h(SparseParams P) { sparse_h_body(P); }
 __global__ __launch_bounds__(256, 1) void k_sparse_v_base(SparseParams P) { sparse_v_base_body(P); }
