@@ -224,7 +224,10 @@ void snesimage_debug_fail_alloc(int32_t n);
  *   ms3[2] = the V pass, the dominant kernel: k_sparse_v2 alone (one launch, the scales at least 64 wide; the wait for
  *            B's checkpoints and k_sparse_order come before the opening event) on the group-sparse path, k_vpass* at
  *            scale 0 otherwise;
- * plus the number of launch groups and the candidates they scored since timing was enabled. */
+ * plus the number of launch groups and the candidates they scored since timing was enabled.
+ * on = 1: all three brackets — six event records per launch group, each a ~4 us bubble in the stream (25 us per group: 1.5 % of a
+ * 4,096-candidate group, 9 % of a 64-candidate one; profiles/r4_timing_cost.py).  on = 2: the V pass's bracket only (ms3[0] and
+ * ms3[1] stay 0): what bench.py keeps on over its timed region.  on = 0: off. */
 int32_t snesimage_timing_enable(snesimage_ctx *ctx, int32_t on);
 int32_t snesimage_timing_read(snesimage_ctx *ctx, double *ms3, uint64_t *launches,
                               uint64_t *candidates);

@@ -7,7 +7,7 @@ cp $L /tmp/libtree.so
 one() { python bench.py --no-extras --no-cpu-baseline "$@" 2>/dev/null | python3 -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print('%-12s n=%-5d value %.0f ms/step %.4f | V %.3f ms H %.3f ms group %.3f ms' % ('$TAG', d['config']['batch'], d['value'], d['ms_per_step'], r['avg_launch_ms'], 0.0, r['group_ms']))"; }
+print('%-12s n=%-5d value %.0f ms/step %.4f | V %.3f ms' % ('$TAG', d['config']['batch'], d['value'], d['ms_per_step'], r['avg_launch_ms']))"; }
 for i in 1 2 3; do
   for f in profiles/ab/lib*.so /tmp/libtree.so; do
     TAG=$(basename $f .so | sed 's/^lib//'); cp $f $L

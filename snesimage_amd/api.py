@@ -95,6 +95,7 @@ class OptimizedImage:
         self._chk(self._L.snesimage_set_chunk(self._c, int(chunk)))
 
     def timing_enable(self, on=True):
+        """True / 1: every bracket (group, H pass, V pass); 2: the V pass's only (two event records per launch group instead of six)."""
         self._chk(self._L.snesimage_timing_enable(self._c, int(on)))
 
     def timing_read(self):

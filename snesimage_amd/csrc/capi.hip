@@ -203,9 +203,9 @@ struct snesimage_ctx {
     uint32_t pend_n = 0, pend_sp = 0, pend_si = 0, pend_method = 0; bool pend = false;
 
     // timing
-    bool timing = false;
+    int timing = 0; // 0 off, 1 every bracket (group, H pass, V pass), 2 the V pass's only (snesimage_timing_enable)
     double t_ms[3] = {0.0, 0.0, 0.0}; uint64_t t_launches = 0, t_cands = 0; // [0] whole launch group, [1] k_hpass scale 0, [2] k_vpass scale 0
-    struct TimingRec { hipEvent_t ev[6]; uint32_t n; };
+    struct TimingRec { hipEvent_t ev[6]; uint32_t n; bool light; }; // light: only ev[3], ev[4] (the V pass) were recorded
     std::vector<TimingRec> t_pending;
 };
 
@@ -356,7 +356,7 @@ int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double
     const bool use_maps = c->dither;
     const uint32_t slot_ci = (sp >= 0) ? (uint32_t)(sp * (int)c->sub_size + si) : 0xffffffffu;
     snesimage_ctx::TimingRec tr{}; tr.n = nc;
-    if (c->timing) { for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&tr.ev[i])); HIPCHK(hipEventRecord(tr.ev[0], c->stream)); }
+    if (c->timing) { for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&tr.ev[i])); if (c->timing == 1) HIPCHK(hipEventRecord(tr.ev[0], c->stream)); }
     hipLaunchKernelGGL(k_candidate_tables, dim3((nc + 63) / 64), dim3(64), 0, c->stream, d_rgb5, (int)nc, c->d_eotf, c->d_cand_tab);
     hipLaunchKernelGGL(k_candidate_slot, dim3((nc + 63) / 64), dim3(64), 0, c->stream, c->d_cand_tab, (int)nc, slot_ci);
     if (c->perceptual) hipLaunchKernelGGL(k_candidate_lab, dim3((nc + 63) / 64), dim3(64), 0, c->stream, c->d_cand_tab, (int)nc, c->d_lab_eotf, c->d_cand_lab);
@@ -392,7 +392,7 @@ int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double
         return F;
     };
     for (int s = 0; s < G.nscales; s++) {
-        if (s == 0 && c->timing) HIPCHK(hipEventRecord(tr.ev[1], c->stream));
+        if (s == 0 && c->timing == 1) HIPCHK(hipEventRecord(tr.ev[1], c->stream));
         if (is_fast(s)) {
             FastParams F = fast_params(s);
             dim3 grid((unsigned)(npairs * (G.sh[s] / 64)));
@@ -409,7 +409,7 @@ int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double
                 else hipLaunchKernelGGL((k_hpass<true, false>), grid, dim3(256), 0, c->stream, Hp);
             } else hipLaunchKernelGGL((k_hpass<false, false>), grid, dim3(256), 0, c->stream, Hp);
         }
-        if (s == 0 && c->timing) HIPCHK(hipEventRecord(tr.ev[2], c->stream));
+        if (s == 0 && c->timing == 1) HIPCHK(hipEventRecord(tr.ev[2], c->stream));
         // the V pass of the same scale follows immediately, while its H output is still cache-resident
         if (s == 0 && c->timing) HIPCHK(hipEventRecord(tr.ev[3], c->stream));
         int ppv = 256 / G.sw[s];
@@ -433,7 +433,7 @@ int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double
     hipLaunchKernelGGL(k_final_score, dim3((nc + 63) / 64), dim3(64), 0, c->stream, c->d_part, (int)nc, G, d_errors, err_stride, err_offset);
     if (use_maps) hipLaunchKernelGGL(k_keep_best, dim3(1), dim3(1024), 0, c->stream, d_errors, err_stride, err_offset, (int)nc, c->d_maps, (int)c->npx, c->d_bestrec, c->d_bestmap);
     HIPCHK(hipGetLastError());
-    if (c->timing) { HIPCHK(hipEventRecord(tr.ev[5], c->stream)); c->t_pending.push_back(tr); }
+    if (c->timing) { tr.light = c->timing != 1; if (!tr.light) HIPCHK(hipEventRecord(tr.ev[5], c->stream)); c->t_pending.push_back(tr); }
     return SNES_OK;
 }
 
@@ -643,7 +643,7 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
     SparseParams P = sparse_params(c, lane);
     P.is_base = 0; P.ncand = (int)nc; P.k0 = (int)(lane * sp.cap);
     snesimage_ctx::TimingRec tr{}; tr.n = nc;
-    if (c->timing) { for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&tr.ev[i])); HIPCHK(hipEventRecord(tr.ev[0], stream)); }
+    if (c->timing) { for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&tr.ev[i])); if (c->timing == 1) HIPCHK(hipEventRecord(tr.ev[0], stream)); }
     hipLaunchKernelGGL(k_candidate_tables, dim3((nc + 63) / 64), dim3(64), 0, stream, d_rgb5, (int)nc, c->d_eotf, sp.cand_tab + 8 * (size_t)P.k0);
     if (c->dither) { // first pixel each candidate takes from B, then its own Floyd-Steinberg run from that 4-row group on
         if (c->perceptual) {
@@ -686,7 +686,7 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
         hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P, -2);
     } else hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P, 0);
     if (sp.side) HIPCHK(hipStreamWaitEvent(stream, sp.ev_base_h, 0)); // B's H-pass checkpoints (a short list gets here before B's sweep is through)
-    if (c->timing) HIPCHK(hipEventRecord(tr.ev[1], stream)); // ev[1]..ev[2]: the candidates' H pass alone (the wait for B's sweep is before it)
+    if (c->timing == 1) HIPCHK(hipEventRecord(tr.ev[1], stream)); // ev[1]..ev[2]: the candidates' H pass alone (the wait for B's sweep is before it)
     { size_t gx = ((size_t)nc * (G.sh[0] / 4) * 3 + 15) / 16; if (gx > sp.hgrid) gx = sp.hgrid; // grid-stride over the item quads
       if (nc <= sp.h2q_max) { // a short list: the H pass with a quad of lanes per row (a third of the chain, four times the waves)
           size_t gq = ((size_t)nc * (G.sh[0] / 4) * 3 + 3) / 4; if (gq > sp.hgrid) gq = sp.hgrid;
@@ -694,7 +694,7 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
       } else
       hipLaunchKernelGGL(k_sparse_h2, dim3((unsigned)gx, (unsigned)(P.s_first * kColBuckets)), dim3(64), h2_lds(c), stream, P);
       if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((gx + 7) / 8), (unsigned)((G.nscales - P.s_first) * kColBuckets)), dim3(64), 0, stream, P); }
-    if (c->timing) HIPCHK(hipEventRecord(tr.ev[2], stream));
+    if (c->timing == 1) HIPCHK(hipEventRecord(tr.ev[2], stream));
     if (sp.side || stream != c->stream) HIPCHK(hipStreamWaitEvent(stream, sp.side ? sp.ev_base_done : c->ev_ready, 0)); // checkpoints and H output of B
     if (c->sp.lpt && nc > 512) { // (a short list's blocks are all resident at once: their order is immaterial)
         hipLaunchKernelGGL(k_sparse_order, dim3(1), dim3(1024), 0, stream, P, sp.order + P.k0); P.order = sp.order + P.k0;
@@ -710,7 +710,7 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
         hipLaunchKernelGGL(k_keep_best, dim3(1), dim3(1024), 0, stream, d_errors, err_stride, err_offset, (int)nc, P.maps, (int)c->npx, br, bm);
     }
     HIPCHK(hipGetLastError());
-    if (c->timing) { HIPCHK(hipEventRecord(tr.ev[5], stream)); c->t_pending.push_back(tr); }
+    if (c->timing) { tr.light = c->timing != 1; if (!tr.light) HIPCHK(hipEventRecord(tr.ev[5], stream)); c->t_pending.push_back(tr); }
     return SNES_OK;
 }
 
@@ -832,9 +832,11 @@ int32_t set_device(snesimage_ctx *c) { HIPCHK(hipSetDevice(c->device)); return c
 int32_t drain_timing(snesimage_ctx *c) {
     for (auto &r : c->t_pending) {
         float ms = 0.0f;
-        HIPCHK(hipEventSynchronize(r.ev[5]));
-        HIPCHK(hipEventElapsedTime(&ms, r.ev[0], r.ev[5])); c->t_ms[0] += ms;
-        HIPCHK(hipEventElapsedTime(&ms, r.ev[1], r.ev[2])); c->t_ms[1] += ms;
+        HIPCHK(hipEventSynchronize(r.ev[r.light ? 4 : 5]));
+        if (!r.light) {
+            HIPCHK(hipEventElapsedTime(&ms, r.ev[0], r.ev[5])); c->t_ms[0] += ms;
+            HIPCHK(hipEventElapsedTime(&ms, r.ev[1], r.ev[2])); c->t_ms[1] += ms;
+        }
         HIPCHK(hipEventElapsedTime(&ms, r.ev[3], r.ev[4])); c->t_ms[2] += ms;
         c->t_launches += 1; c->t_cands += r.n;
         for (int i = 0; i < 6; i++) (void)hipEventDestroy(r.ev[i]);
@@ -1397,7 +1399,7 @@ int32_t snesimage_timing_enable(snesimage_ctx *c, int32_t on) {
     CHECK(set_device(c));
     HIPCHK(hipStreamSynchronize(c->stream));
     CHECK(drain_timing(c));
-    c->timing = on != 0; c->t_ms[0] = c->t_ms[1] = c->t_ms[2] = 0.0; c->t_launches = 0; c->t_cands = 0;
+    c->timing = on == 2 ? 2 : (on != 0 ? 1 : 0); c->t_ms[0] = c->t_ms[1] = c->t_ms[2] = 0.0; c->t_launches = 0; c->t_cands = 0;
     return SNES_OK;
 }
 int32_t snesimage_timing_read(snesimage_ctx *c, double *ms3, uint64_t *launches, uint64_t *candidates) {

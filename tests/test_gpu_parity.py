@@ -1014,3 +1014,27 @@ def test_small_heights_sparse_path_equals_dense_path(S, O, h, flags, monkeypatch
     assert stats["windows"] < 40
     dense.close()
     sparse.close()
+
+
+@pytest.mark.gpu
+def test_launch_timing_levels_leave_the_results_alone(S, img256):
+    """snesimage_timing_enable: 1 = every bracket (group, H pass, V pass), 2 = the V pass's only (what bench.py keeps on over its
+    timed region: two event records per launch group instead of six).  Same errors either way and with timing off."""
+    g = S.OptimizedImage(img256, 4, 7)
+    g.initialize_tiles()
+    g.recalculate_palettes()
+    g.optimize()
+    cand = S.random_candidates(5, 11, 200)
+    want = g.score_candidates(2, 3, cand)
+    for level in (1, 2):
+        g.timing_enable(level)
+        got = g.score_candidates(2, 3, cand)
+        t = g.timing_read()
+        g.timing_enable(False)
+        assert np.array_equal(got, want)
+        assert t["launches"] >= 1 and t["candidates"] == 200 and t["vpass0_ms"] > 0.0
+        if level == 1:
+            assert t["group_ms"] >= t["vpass0_ms"] and t["hpass0_ms"] > 0.0
+        else:
+            assert t["group_ms"] == 0.0 and t["hpass0_ms"] == 0.0
+    g.close()
