@@ -152,6 +152,12 @@ struct snesimage_ctx {
         bool counters_cleared = false; // k_prep cleared B's counters for the current pack
         uint32_t h2q_max = 512; // longest list that takes k_sparse_h2q (SNES_H2Q_MAX; 0 = never)
         bool down_tiles = true; // scales 2.. of the candidates' downscale one block per changed group of scale 3 (SNES_DOWN_TILES=0: k_sparse_down, one block per candidate, scale after scale)
+        // The H pass of scale 0 — three quarters of the H pass, bound by its stores — reads the pack and B's checkpoints, not the
+        // downscale; the downscale is bound by its arithmetic.  Launch groups of h0_min candidates and more run the two side by side:
+        // scale 0's lists on a stream of their own from the scan on, the other wide scales behind the downscale as before.
+        uint32_t h0_min = 1024; // (SNES_H0_MIN; 0 = never)
+        uint32_t h0_grid = 8192; // most blocks per list of that launch (SNES_H0_GRID)
+        hipStream_t h0_stream[8] = {}; hipEvent_t ev_scan[8] = {}, ev_h0[8] = {};
         uint32_t tiles_grid = 4096; // most blocks of k_sparse_down_tiles (SNES_TILES_GRID)
         uint32_t down1_grid = 32768; // most blocks of k_sparse_down1 (SNES_DOWN1_GRID)
         bool vsplit = true; // B's wide V sweep with recurrences and maps on two waves (k_sparse_v2_base_split; SNES_VSPLIT=0: one wave does both)
@@ -676,6 +682,21 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
         hipLaunchKernelGGL(k_sparse_scan_lab, dim3(nc), dim3(256), 0, stream, P);
     } else if (nc <= sp.scan4_max) hipLaunchKernelGGL(k_sparse_scan4, dim3((nc + 3) / 4), dim3(1024), 0, stream, P); // a list that leaves CUs idle: four waves per candidate, a quarter of the chain
     else hipLaunchKernelGGL(k_sparse_scan, dim3((nc + 15) / 16), dim3(1024), 0, stream, P);
+    const bool h0_ahead = sp.side && sp.h0_min > 0 && nc >= sp.h0_min && nc > sp.h2q_max && lane < 8 && P.s_first > 0;
+    if (h0_ahead) {
+        if (!sp.h0_stream[lane]) {
+            HIPCHK(hipStreamCreateWithFlags(&sp.h0_stream[lane], hipStreamNonBlocking)); // (default priority: a lower or a higher one than the main stream's costs 40-50 % of the step)
+            HIPCHK(hipEventCreateWithFlags(&sp.ev_scan[lane], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&sp.ev_h0[lane], hipEventDisableTiming));
+        }
+        hipStream_t hs = sp.h0_stream[lane];
+        HIPCHK(hipEventRecord(sp.ev_scan[lane], stream));
+        HIPCHK(hipStreamWaitEvent(hs, sp.ev_scan[lane], 0));  // the work items
+        HIPCHK(hipStreamWaitEvent(hs, sp.ev_base_h, 0));      // B's H-pass checkpoints
+        size_t gx = ((size_t)nc * (G.sh[0] / 4) * 3 + 15) / 16; if (gx > sp.h0_grid) gx = sp.h0_grid;
+        hipLaunchKernelGGL(k_sparse_h2, dim3((unsigned)gx, (unsigned)kColBuckets), dim3(64), h2_lds(c), hs, P); // grid.y = scale 0's lists only
+        HIPCHK(hipEventRecord(sp.ev_h0[lane], hs));
+    }
     if (sp.down1 && G.nscales > 2) { // scale 1 one block per changed group (the scan's item lists name them), then the scales that do depend on each other
         size_t gd = (size_t)nc * 8; if (gd > sp.down1_grid) gd = sp.down1_grid; // (~6 changed groups per candidate; grid-stride beyond)
         hipLaunchKernelGGL(k_sparse_down1, dim3((unsigned)gd), dim3(256), 0, stream, P);
@@ -692,8 +713,11 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
           size_t gq = ((size_t)nc * (G.sh[0] / 4) * 3 + 3) / 4; if (gq > sp.hgrid) gq = sp.hgrid;
           hipLaunchKernelGGL(k_sparse_h2q, dim3((unsigned)gq, (unsigned)(P.s_first * kColBuckets)), dim3(64), h2_lds(c), stream, P);
       } else
+      if (h0_ahead) { if (P.s_first > 1) hipLaunchKernelGGL(k_sparse_h2_from, dim3((unsigned)gx, (unsigned)((P.s_first - 1) * kColBuckets)), dim3(64), h2_lds(c), stream, P, (int)kColBuckets); } // (scale 0's lists went ahead)
+      else
       hipLaunchKernelGGL(k_sparse_h2, dim3((unsigned)gx, (unsigned)(P.s_first * kColBuckets)), dim3(64), h2_lds(c), stream, P);
-      if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((gx + 7) / 8), (unsigned)((G.nscales - P.s_first) * kColBuckets)), dim3(64), 0, stream, P); }
+      if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((gx + 7) / 8), (unsigned)((G.nscales - P.s_first) * kColBuckets)), dim3(64), 0, stream, P);
+      if (h0_ahead) HIPCHK(hipStreamWaitEvent(stream, sp.ev_h0[lane], 0)); }
     if (c->timing == 1) HIPCHK(hipEventRecord(tr.ev[2], stream));
     if (sp.side || stream != c->stream) HIPCHK(hipStreamWaitEvent(stream, sp.side ? sp.ev_base_done : c->ev_ready, 0)); // checkpoints and H output of B
     if (c->sp.lpt && nc > 512) { // (a short list's blocks are all resident at once: their order is immaterial)
@@ -942,6 +966,8 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     if (const char *e = getenv("SNES_DOWN1_GRID")) { int v = atoi(e); if (v >= 64) c->sp.down1_grid = (uint32_t)v; }
     if (const char *e = getenv("SNES_VSPLIT")) c->sp.vsplit = atoi(e) != 0;
     if (const char *e = getenv("SNES_DOWN_TILES")) c->sp.down_tiles = atoi(e) != 0;
+    if (const char *e = getenv("SNES_H0_GRID")) { int v = atoi(e); if (v >= 16) c->sp.h0_grid = (uint32_t)v; }
+    if (const char *e = getenv("SNES_H0_MIN")) { int v = atoi(e); if (v >= 0) c->sp.h0_min = (uint32_t)v; }
     if (const char *e = getenv("SNES_TILES_GRID")) { int v = atoi(e); if (v >= 64) c->sp.tiles_grid = (uint32_t)v; }
     if (const char *e = getenv("SNES_SCAN4_MAX")) { int v = atoi(e); if (v >= 0) c->sp.scan4_max = (uint32_t)v; }
     if (const char *e = getenv("SNES_H2Q_MAX")) { int v = atoi(e); if (v >= 0) c->sp.h2q_max = (uint32_t)v; }
@@ -1043,7 +1069,8 @@ void snesimage_destroy(snesimage_ctx *c) {
     dfree(c->d_cand); dfree(c->d_cand_sel); dfree(c->d_errs); dfree(c->d_errs_sel); dfree(c->d_inc_err); dfree(c->d_last); dfree(c->d_scratch_err); dfree(c->d_dummy_cand);
     for (auto &L : c->extra) { if (L.stream) (void)hipStreamSynchronize(L.stream); dfree(L.d_mapsC4); dfree(L.d_mapsR4); dfree(L.d_work); dfree(L.d_cand_tab); dfree(L.d_cand_lab); dfree(L.d_part); dfree(L.d_maps); dfree(L.d_mapsT); if (L.done) (void)hipEventDestroy(L.done); if (L.stream) (void)hipStreamDestroy(L.stream); }
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
-    { auto &q = c->sp; if (q.base_stream) { (void)hipStreamSynchronize(q.base_stream); (void)hipStreamDestroy(q.base_stream); (void)hipEventDestroy(q.ev_base_in); (void)hipEventDestroy(q.ev_base_h); (void)hipEventDestroy(q.ev_base_narrow); (void)hipEventDestroy(q.ev_base_done); } dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.order); dfree(q.first); dfree(q.cand_lab); dfree(q.bitmap); dfree(q.ckh);
+    { auto &q = c->sp; for (int i = 0; i < 8; i++) if (q.h0_stream[i]) { (void)hipStreamSynchronize(q.h0_stream[i]); (void)hipStreamDestroy(q.h0_stream[i]); (void)hipEventDestroy(q.ev_scan[i]); (void)hipEventDestroy(q.ev_h0[i]); }
+      if (q.base_stream) { (void)hipStreamSynchronize(q.base_stream); (void)hipStreamDestroy(q.base_stream); (void)hipEventDestroy(q.ev_base_in); (void)hipEventDestroy(q.ev_base_h); (void)hipEventDestroy(q.ev_base_narrow); (void)hipEventDestroy(q.ev_base_done); } dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.order); dfree(q.first); dfree(q.cand_lab); dfree(q.bitmap); dfree(q.ckh);
       dfree(q.dmaps); dfree(q.dmapsC4); dfree(q.bmap); dfree(q.bmapC4); dfree(q.bcand); dfree(q.dpack); dfree(q.ckd);
       dfree(q.rec_lab); dfree(q.ahead.blab); dfree(q.ahead.rec_lab); dfree(q.ahead.bmap); dfree(q.ahead.bmapC4); dfree(q.ahead.bcand); dfree(q.ahead.dpack); dfree(q.ahead.ckd); dfree(q.ahead.btab); dfree(q.ahead.ok); if (q.ahead.ev) (void)hipEventDestroy(q.ahead.ev); }
     kmeans_free(c->km);

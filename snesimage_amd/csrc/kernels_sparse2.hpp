@@ -727,6 +727,8 @@ __device__ __forceinline__ void sparse_h2_dispatch(const SparseParams &P, const 
     if (s == 0) sparse_h2_body<true, BASE>(P, list, bx, gx, sh); else sparse_h2_body<false, BASE>(P, list, bx, gx, sh);
 }
 __global__ __launch_bounds__(64) void k_sparse_h2(SparseParams P) { sparse_h2_dispatch<false>(P, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x); }
+// the lists from list0 on (the launch that follows the downscale when scale 0's lists, which do not read it, went ahead beside it)
+__global__ __launch_bounds__(64) void k_sparse_h2_from(SparseParams P, int list0) { sparse_h2_dispatch<false>(P, list0 + (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x); }
 __global__ __launch_bounds__(64) void k_sparse_h2q(SparseParams P) { sparse_h2q_dispatch<false>(P, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x); } // short lists
 __global__ __launch_bounds__(64) void k_sparse_h2q_base(SparseParams P) { sparse_h2q_dispatch<true>(P, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x); } // B: a single image is a short list
 __global__ __launch_bounds__(64) void k_sparse_h2_base(SparseParams P) { sparse_h2_dispatch<true>(P, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x); }

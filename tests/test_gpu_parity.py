@@ -621,7 +621,7 @@ def test_sparse_path_equals_dense_path(S, O, seed, variant, perceptual, monkeypa
 
 @pytest.mark.parametrize("flags", [{"dither": True}, {"perceptual": True}, {}], ids=["dither", "perceptual", "rgb"])
 @pytest.mark.parametrize("knobs", [{}, {"SNES_H2Q_MAX": "0", "SNES_DITHER4_MAX": "0"}, {"SNES_H2Q_MAX": "100000", "SNES_DITHER4_MAX": "100000"},
-                                   {"SNES_VSPLIT": "0", "SNES_SCAN4_MAX": "0", "SNES_DOWN_TILES": "0"}, {"SNES_SCAN4_MAX": "100000"}],
+                                   {"SNES_VSPLIT": "0", "SNES_SCAN4_MAX": "0", "SNES_DOWN_TILES": "0", "SNES_H0_MIN": "0"}, {"SNES_SCAN4_MAX": "100000"}],
                          ids=["default", "one-lane", "quad", "round3-base-sweep-scan-and-downscale", "scan4-everywhere"])
 def test_long_lists_pin_both_kernel_families(S, img256_alpha, flags, knobs, monkeypatch):
     """Launch groups of more than 512 candidates take the one-lane H pass (k_sparse_h2) and the one-lane resumed
@@ -630,7 +630,8 @@ def test_long_lists_pin_both_kernel_families(S, img256_alpha, flags, knobs, monk
     thresholds and with each family forced everywhere, against the dense path (SNES_SPARSE=0), bit for bit.  Round 4's
     variants ride along: B's V sweep on one wave instead of two (SNES_VSPLIT=0), the scan with one wave per candidate or
     four everywhere (SNES_SCAN4_MAX), the candidates' scales 2.. a block per candidate instead of a block per changed group of
-    scale 3 (SNES_DOWN_TILES=0)."""
+    scale 3 (SNES_DOWN_TILES=0), the H pass of scale 0 behind the downscale instead of beside it on a stream of its own
+    (SNES_H0_MIN=0; the default takes the side-by-side path for the 1,100-candidate list)."""
     monkeypatch.setenv("SNES_SPARSE", "0")
     dense = S.OptimizedImage(img256_alpha, 8, 15, **flags)
     monkeypatch.delenv("SNES_SPARSE")
