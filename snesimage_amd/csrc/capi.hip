@@ -156,8 +156,12 @@ struct snesimage_ctx {
         // downscale; the downscale is bound by its arithmetic.  Launch groups of h0_min candidates and more run the two side by side:
         // scale 0's lists on a stream of their own from the scan on, the other wide scales behind the downscale as before.
         uint32_t h0_min = 1024; // (SNES_H0_MIN; 0 = never)
+        bool base_down_side = false; // B's planes in place were downscaled on B's stream: their readers wait for ev_base_h (sparse_base_pass)
         uint32_t h0_grid = 8192; // most blocks per list of that launch (SNES_H0_GRID)
-        hipStream_t h0_stream[8] = {}; hipEvent_t ev_scan[8] = {}, ev_h0[8] = {};
+        hipStream_t h0_stream[8] = {}; hipEvent_t ev_scan[8] = {}, ev_h0[8] = {}, ev_hn[8] = {}, ev_vn[8] = {};
+        bool v0_aside = true; // and scale 0's V pass behind its H pass on that stream, beside everything else of the group (SNES_V0_ASIDE=0: one V launch on the main stream)
+        hipEvent_t ev_v0[8] = {};
+        bool vn_aside = true; // with it, the narrow scales' V pass on that stream beside the wide scales' (SNES_VN_ASIDE=0: behind it)
         uint32_t tiles_grid = 4096; // most blocks of k_sparse_down_tiles (SNES_TILES_GRID)
         uint32_t down1_grid = 32768; // most blocks of k_sparse_down1 (SNES_DOWN1_GRID)
         bool vsplit = true; // B's wide V sweep with recurrences and maps on two waves (k_sparse_v2_base_split; SNES_VSPLIT=0: one wave does both)
@@ -549,7 +553,7 @@ SparseParams sparse_params(snesimage_ctx *c, uint32_t lane) {
 static size_t h2_lds(const snesimage_ctx *c) { return sizeof(float) * 3 * (size_t)(c->ncol + 2); } // k_sparse_h2's palette table in LDS
 
 // B of the current slot: compact list of contested pixels, then the pipeline once with checkpoints (main stream)
-int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si) {
+int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si, uint32_t n_cand) { // n_cand: candidates of the call (decides where B's downscale runs)
     auto &sp = c->sp;
     const Geom &G = c->G;
     if (!sp.plist_valid) {
@@ -593,13 +597,20 @@ int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si) {
         hipLaunchKernelGGL(k_build_plist, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, win_pack, (int)c->npx, sp.plist, sp.plist_count);
         SparseParams P = sparse_params(c, c->nlanes); // B has its own item list and counters
         P.is_base = 1; P.ncand = 1; P.k0 = P.base;
-        hipLaunchKernelGGL(k_base_down, dim3((unsigned)((G.W / 32) * ((G.H + 31) / 32))), dim3(256), 0, c->stream, P); // B: every row of every scale
         // B's H and V passes are long single-image sweeps (latency-bound); they run on their own stream beside the
         // candidates' scan / downscale / H pass, which only need B's linear-RGB rows.  The candidates' V pass waits for them.
         // (SNES_BASE_STREAM=0 keeps them on the context's stream: with many contexts on one device the extra streams only
         // add cross-queue waits.)
         hipStream_t bs = sp.side ? sp.base_stream : c->stream;
+        // B's downscale goes with its sweeps where the call is long (round 4: it was the main stream's, 12 us in front of every call's
+        // candidates): the pack and the contested list are what the candidates' scan and scale-1 downscale read; B's planes are first
+        // read by the downscale of scales 2.., which waits for ev_base_h.  A short call waits for B's chain: there the downscale stays
+        // in front of the hand-over, which would only delay it (0.267 -> 0.279 ms per 64-candidate call the other way).
+        const bool down_with_sweeps = sp.side && n_cand >= sp.h0_min && sp.h0_min > 0;
+        sp.base_down_side = down_with_sweeps;
+        if (!down_with_sweeps) hipLaunchKernelGGL(k_base_down, dim3((unsigned)((G.W / 32) * ((G.H + 31) / 32))), dim3(256), 0, c->stream, P); // B: every row of every scale
         if (sp.side) { HIPCHK(hipEventRecord(sp.ev_base_in, c->stream)); HIPCHK(hipStreamWaitEvent(bs, sp.ev_base_in, 0)); }
+        if (down_with_sweeps) hipLaunchKernelGGL(k_base_down, dim3((unsigned)((G.W / 32) * ((G.H + 31) / 32))), dim3(256), 0, bs, P);
         hipLaunchKernelGGL(k_sparse_scan, dim3(1), dim3(1024), 0, bs, P); // B's work items (every group, from column 0): only B's own sweeps read them
         // wide scales: B rows start at column 0 (list s*kColBuckets) and leave the per-block H checkpoints and the scale-0 XYB plane
         if (sp.h2q_max > 0) hipLaunchKernelGGL(k_sparse_h2q_base, dim3((unsigned)((G.sh[0] / 4 * 3 + 3) / 4), (unsigned)(P.s_first * kColBuckets)), dim3(64), h2_lds(c), bs, P);
@@ -682,12 +693,19 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
         hipLaunchKernelGGL(k_sparse_scan_lab, dim3(nc), dim3(256), 0, stream, P);
     } else if (nc <= sp.scan4_max) hipLaunchKernelGGL(k_sparse_scan4, dim3((nc + 3) / 4), dim3(1024), 0, stream, P); // a list that leaves CUs idle: four waves per candidate, a quarter of the chain
     else hipLaunchKernelGGL(k_sparse_scan, dim3((nc + 15) / 16), dim3(1024), 0, stream, P);
+    bool vn_aside = false;
     const bool h0_ahead = sp.side && sp.h0_min > 0 && nc >= sp.h0_min && nc > sp.h2q_max && lane < 8 && P.s_first > 0;
+    const bool v0_aside = h0_ahead && sp.v0_aside;
+    vn_aside = h0_ahead && !v0_aside && sp.vn_aside && P.s_first < G.nscales;
+    if (c->sp.lpt && nc > 512) P.order = sp.order + P.k0; // (written by k_sparse_order before any V pass reads it)
     if (h0_ahead) {
         if (!sp.h0_stream[lane]) {
             HIPCHK(hipStreamCreateWithFlags(&sp.h0_stream[lane], hipStreamNonBlocking)); // (default priority: a lower or a higher one than the main stream's costs 40-50 % of the step)
             HIPCHK(hipEventCreateWithFlags(&sp.ev_scan[lane], hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&sp.ev_h0[lane], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&sp.ev_hn[lane], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&sp.ev_v0[lane], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&sp.ev_vn[lane], hipEventDisableTiming));
         }
         hipStream_t hs = sp.h0_stream[lane];
         HIPCHK(hipEventRecord(sp.ev_scan[lane], stream));
@@ -695,18 +713,27 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
         HIPCHK(hipStreamWaitEvent(hs, sp.ev_base_h, 0));      // B's H-pass checkpoints
         size_t gx = ((size_t)nc * (G.sh[0] / 4) * 3 + 15) / 16; if (gx > sp.h0_grid) gx = sp.h0_grid;
         hipLaunchKernelGGL(k_sparse_h2, dim3((unsigned)gx, (unsigned)kColBuckets), dim3(64), h2_lds(c), hs, P); // grid.y = scale 0's lists only
+        if (c->sp.lpt) hipLaunchKernelGGL(k_sparse_order, dim3(1), dim3(1024), 0, hs, P, sp.order + P.k0); // (the V pass's order needs the scan only: off the main stream)
         HIPCHK(hipEventRecord(sp.ev_h0[lane], hs));
+        if (v0_aside) { // scale 0's V pass needs scale 0's H pass, B's sweeps and the order: nothing of the main stream's
+            HIPCHK(hipStreamWaitEvent(hs, sp.ev_base_done, 0)); // checkpoints and H output of B
+            if (c->timing) HIPCHK(hipEventRecord(tr.ev[3], hs));
+            hipLaunchKernelGGL(k_sparse_v2, dim3(nc * 3, 1), dim3(256), 0, hs, P); // grid.y = scale 0 only
+            if (c->timing) HIPCHK(hipEventRecord(tr.ev[4], hs)); // ev[3]..ev[4]: k_sparse_v2 (scale 0: three quarters of the V pass) alone
+            HIPCHK(hipEventRecord(sp.ev_v0[lane], hs));
+        }
     }
     if (sp.down1 && G.nscales > 2) { // scale 1 one block per changed group (the scan's item lists name them), then the scales that do depend on each other
         size_t gd = (size_t)nc * 8; if (gd > sp.down1_grid) gd = sp.down1_grid; // (~6 changed groups per candidate; grid-stride beyond)
         hipLaunchKernelGGL(k_sparse_down1, dim3((unsigned)gd), dim3(256), 0, stream, P);
+        if (sp.side && sp.base_down_side) HIPCHK(hipStreamWaitEvent(stream, sp.ev_base_h, 0)); // B's planes (downscaled on B's stream) and, for later, its H-pass checkpoints
         if (sp.down_tiles && G.nscales >= 4) { // scales 2..: one block per changed group of scale 3
             size_t gt = ((size_t)nc * (G.sh[3] / 4) + SNES_DOWN_TILES_U - 1) / SNES_DOWN_TILES_U; if (gt > sp.tiles_grid) gt = sp.tiles_grid; // (4-5 of a candidate's 8 groups change; the block takes SNES_DOWN_TILES_U at a time, grid-stride beyond)
-            hipLaunchKernelGGL(k_sparse_down_tiles, dim3((unsigned)gt), dim3(512), 0, stream, P);
+            hipLaunchKernelGGL(k_sparse_down_tiles, dim3((unsigned)gt), dim3(256), 0, stream, P);
         } else
         hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P, -2);
-    } else hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P, 0);
-    if (sp.side) HIPCHK(hipStreamWaitEvent(stream, sp.ev_base_h, 0)); // B's H-pass checkpoints (a short list gets here before B's sweep is through)
+    } else { if (sp.side && sp.base_down_side) HIPCHK(hipStreamWaitEvent(stream, sp.ev_base_h, 0)); hipLaunchKernelGGL(k_sparse_down, dim3(nc), dim3(256), 0, stream, P, 0); }
+    if (sp.side && !sp.base_down_side) HIPCHK(hipStreamWaitEvent(stream, sp.ev_base_h, 0)); // B's H-pass checkpoints (a short list gets here before B's sweep is through)
     if (c->timing == 1) HIPCHK(hipEventRecord(tr.ev[1], stream)); // ev[1]..ev[2]: the candidates' H pass alone (the wait for B's sweep is before it)
     { size_t gx = ((size_t)nc * (G.sh[0] / 4) * 3 + 15) / 16; if (gx > sp.hgrid) gx = sp.hgrid; // grid-stride over the item quads
       if (nc <= sp.h2q_max) { // a short list: the H pass with a quad of lanes per row (a third of the chain, four times the waves)
@@ -717,17 +744,36 @@ int32_t sparse_score_chunk(snesimage_ctx *c, uint32_t lane, hipStream_t stream, 
       else
       hipLaunchKernelGGL(k_sparse_h2, dim3((unsigned)gx, (unsigned)(P.s_first * kColBuckets)), dim3(64), h2_lds(c), stream, P);
       if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_h, dim3((unsigned)((gx + 7) / 8), (unsigned)((G.nscales - P.s_first) * kColBuckets)), dim3(64), 0, stream, P);
+      if (vn_aside) HIPCHK(hipEventRecord(sp.ev_hn[lane], stream)); // the narrow scales' H output is in place
       if (h0_ahead) HIPCHK(hipStreamWaitEvent(stream, sp.ev_h0[lane], 0)); }
     if (c->timing == 1) HIPCHK(hipEventRecord(tr.ev[2], stream));
     if (sp.side || stream != c->stream) HIPCHK(hipStreamWaitEvent(stream, sp.side ? sp.ev_base_done : c->ev_ready, 0)); // checkpoints and H output of B
     if (c->sp.lpt && nc > 512) { // (a short list's blocks are all resident at once: their order is immaterial)
-        hipLaunchKernelGGL(k_sparse_order, dim3(1), dim3(1024), 0, stream, P, sp.order + P.k0); P.order = sp.order + P.k0;
+        if (!h0_ahead) hipLaunchKernelGGL(k_sparse_order, dim3(1), dim3(1024), 0, stream, P, sp.order + P.k0);
+        P.order = sp.order + P.k0;
     }
+    if (vn_aside) { // the narrow scales' V pass — a tenth of the V pass's time, latency-bound — beside the wide scales' instead of behind it
+        hipStream_t hs = sp.h0_stream[lane];
+        HIPCHK(hipStreamWaitEvent(hs, sp.ev_hn[lane], 0));
+        HIPCHK(hipStreamWaitEvent(hs, sp.ev_base_narrow, 0)); // B's narrow-scale sweeps
+        hipLaunchKernelGGL(k_sparse_v, dim3((nc * 3 + 7) / 8, (unsigned)(G.nscales - P.s_first)), dim3(256), 0, hs, P);
+        HIPCHK(hipEventRecord(sp.ev_vn[lane], hs));
+    }
+    if (v0_aside) { // scale 0 runs on the other stream; here the narrow scales first (a latency-bound 55 us that would otherwise end the group alone on the chip), then scales 1..
+        if (sp.side) HIPCHK(hipStreamWaitEvent(stream, sp.ev_base_narrow, 0)); // B's narrow-scale sweeps
+        if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_v, dim3((nc * 3 + 7) / 8, (unsigned)(G.nscales - P.s_first)), dim3(256), 0, stream, P);
+        if (P.s_first > 1) hipLaunchKernelGGL(k_sparse_v2_from, dim3(nc * 3, (unsigned)(P.s_first - 1)), dim3(256), 0, stream, P, 1);
+    } else {
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[3], stream));
     hipLaunchKernelGGL(k_sparse_v2, dim3(nc * 3, (unsigned)P.s_first), dim3(256), 0, stream, P);
     if (c->timing) HIPCHK(hipEventRecord(tr.ev[4], stream)); // ev[3]..ev[4]: k_sparse_v2 alone
+    }
+    if (vn_aside) HIPCHK(hipStreamWaitEvent(stream, sp.ev_vn[lane], 0));
+    else if (!v0_aside) {
     if (sp.side) HIPCHK(hipStreamWaitEvent(stream, sp.ev_base_narrow, 0)); // B's narrow-scale sweeps
     if (P.s_first < G.nscales) hipLaunchKernelGGL(k_sparse_v, dim3((nc * 3 + 7) / 8, (unsigned)(G.nscales - P.s_first)), dim3(256), 0, stream, P); // narrow scales: >= 8 pairs per block
+    }
+    if (v0_aside) HIPCHK(hipStreamWaitEvent(stream, sp.ev_v0[lane], 0));
     hipLaunchKernelGGL(k_final_score_wave, dim3((nc + 3) / 4), dim3(256), 0, stream, sp.part + (size_t)P.k0 * G.nscales * 18, (int)nc, G, d_errors, err_stride, err_offset, P.item_count, (int)kItemLists);
     if (c->dither) { // the lane remembers the map of its best candidate so far: the commit adopts the winner's instead of dithering again
         uint8_t *bm = lane == 0 ? c->d_bestmap : c->extra[lane - 1].d_bestmap; BestRec *br = lane == 0 ? c->d_bestrec : c->extra[lane - 1].d_bestrec;
@@ -770,7 +816,7 @@ int32_t score_list(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t n, double *
     if (sparse) {
         CHECK(sparse_alloc(c, chunk));
         if (c->dither && (c->sp.base_sp != sp || c->sp.base_si != si)) c->sp.plist_valid = false;
-        CHECK(sparse_base_pass(c, sp, si));
+        CHECK(sparse_base_pass(c, sp, si, n));
         c->sp.base_sp = sp; c->sp.base_si = si;
     }
     if (c->dither) { hipLaunchKernelGGL(k_reset_best, dim3(1), dim3(64), 0, c->stream, c->d_bestrecs_all, (int)c->nlanes); c->best_valid = true; }
@@ -966,6 +1012,8 @@ int32_t snesimage_create(const uint8_t *rgba, uint32_t w, uint32_t h, uint32_t s
     if (const char *e = getenv("SNES_DOWN1_GRID")) { int v = atoi(e); if (v >= 64) c->sp.down1_grid = (uint32_t)v; }
     if (const char *e = getenv("SNES_VSPLIT")) c->sp.vsplit = atoi(e) != 0;
     if (const char *e = getenv("SNES_DOWN_TILES")) c->sp.down_tiles = atoi(e) != 0;
+    if (const char *e = getenv("SNES_V0_ASIDE")) c->sp.v0_aside = atoi(e) != 0;
+    if (const char *e = getenv("SNES_VN_ASIDE")) c->sp.vn_aside = atoi(e) != 0;
     if (const char *e = getenv("SNES_H0_GRID")) { int v = atoi(e); if (v >= 16) c->sp.h0_grid = (uint32_t)v; }
     if (const char *e = getenv("SNES_H0_MIN")) { int v = atoi(e); if (v >= 0) c->sp.h0_min = (uint32_t)v; }
     if (const char *e = getenv("SNES_TILES_GRID")) { int v = atoi(e); if (v >= 64) c->sp.tiles_grid = (uint32_t)v; }
@@ -1069,7 +1117,7 @@ void snesimage_destroy(snesimage_ctx *c) {
     dfree(c->d_cand); dfree(c->d_cand_sel); dfree(c->d_errs); dfree(c->d_errs_sel); dfree(c->d_inc_err); dfree(c->d_last); dfree(c->d_scratch_err); dfree(c->d_dummy_cand);
     for (auto &L : c->extra) { if (L.stream) (void)hipStreamSynchronize(L.stream); dfree(L.d_mapsC4); dfree(L.d_mapsR4); dfree(L.d_work); dfree(L.d_cand_tab); dfree(L.d_cand_lab); dfree(L.d_part); dfree(L.d_maps); dfree(L.d_mapsT); if (L.done) (void)hipEventDestroy(L.done); if (L.stream) (void)hipStreamDestroy(L.stream); }
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
-    { auto &q = c->sp; for (int i = 0; i < 8; i++) if (q.h0_stream[i]) { (void)hipStreamSynchronize(q.h0_stream[i]); (void)hipStreamDestroy(q.h0_stream[i]); (void)hipEventDestroy(q.ev_scan[i]); (void)hipEventDestroy(q.ev_h0[i]); }
+    { auto &q = c->sp; for (int i = 0; i < 8; i++) if (q.h0_stream[i]) { (void)hipStreamSynchronize(q.h0_stream[i]); (void)hipStreamDestroy(q.h0_stream[i]); (void)hipEventDestroy(q.ev_scan[i]); (void)hipEventDestroy(q.ev_h0[i]); (void)hipEventDestroy(q.ev_hn[i]); (void)hipEventDestroy(q.ev_vn[i]); (void)hipEventDestroy(q.ev_v0[i]); }
       if (q.base_stream) { (void)hipStreamSynchronize(q.base_stream); (void)hipStreamDestroy(q.base_stream); (void)hipEventDestroy(q.ev_base_in); (void)hipEventDestroy(q.ev_base_h); (void)hipEventDestroy(q.ev_base_narrow); (void)hipEventDestroy(q.ev_base_done); } dfree(q.store); dfree(q.cand_tab); dfree(q.ckf); dfree(q.cka); dfree(q.part); dfree(q.meta); dfree(q.items); dfree(q.item_count); dfree(q.plist); dfree(q.order); dfree(q.first); dfree(q.cand_lab); dfree(q.bitmap); dfree(q.ckh);
       dfree(q.dmaps); dfree(q.dmapsC4); dfree(q.bmap); dfree(q.bmapC4); dfree(q.bcand); dfree(q.dpack); dfree(q.ckd);
       dfree(q.rec_lab); dfree(q.ahead.blab); dfree(q.ahead.rec_lab); dfree(q.ahead.bmap); dfree(q.ahead.bmapC4); dfree(q.ahead.bcand); dfree(q.ahead.dpack); dfree(q.ahead.ckd); dfree(q.ahead.btab); dfree(q.ahead.ok); if (q.ahead.ev) (void)hipEventDestroy(q.ahead.ev); }

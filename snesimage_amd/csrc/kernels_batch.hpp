@@ -70,7 +70,7 @@ __global__ __launch_bounds__(1024) void kb_sparse_scan(const BatchArgs *__restri
 __global__ __launch_bounds__(1024) void kb_sparse_scan4(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; sparse_scan_body<4>(a.Pc); } // four waves per candidate
 __global__ __launch_bounds__(256) void kb_base_down(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; base_down_body(a.Pb); }
 __global__ __launch_bounds__(256) void kb_sparse_down(const BatchArgs *__restrict__ A, int only_scale, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_down_body(a.Pc, only_scale, bb.x); }
-__global__ __launch_bounds__(512) void kb_sparse_down_tiles(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_down_tiles_body<SNES_DOWN_TILES_U>(a.Pc, bb.x, (int)gridDim.x); }
+__global__ __launch_bounds__(256) void kb_sparse_down_tiles(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_down_tiles_body<SNES_DOWN_TILES_U>(a.Pc, bb.x, (int)gridDim.x); }
 __global__ __launch_bounds__(256) void kb_sparse_down1(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_down1_body(a.Pc, bb.x, (int)gridDim.x); }
 __global__ void kb_candidate_tables(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; candidate_tables_body(a.cand, a.n, a.eotf, a.cand_tab); }
 __global__ void kb_candidate_lab(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_IMG; candidate_lab_body(a.cand_tab, a.n, a.lab_eotf, a.cand_lab); }

@@ -621,9 +621,9 @@ __device__ __forceinline__ void sparse_down1_body(const SparseParams &P, const i
 
 // ---- scales 2.. of the candidates' downscale, one block per changed group of scale 3 --------------------------------------
 // sparse_down_body walks a candidate's scales one after the other: every scale reads the linear planes the one before stored,
-// behind a block barrier — four dependent trips to memory for a few thousand pixels.  Here a block of eight waves takes
-// one (candidate, changed group of scale 3): the group's four rows are eight rows of scale 2 — 8 x 64 pixels, one 8 x 8 tile
-// per wave, one pixel per lane, averaged from scale 1 (the candidate's own linear planes where that group changed, B's where
+// behind a block barrier — four dependent trips to memory for a few thousand pixels.  Here a block of four waves takes
+// one (candidate, changed group of scale 3): the group's four rows are eight rows of scale 2 — 8 x 64 pixels, two 8 x 8 tiles
+// per wave, one pixel per lane and tile, averaged from scale 1 (the candidate's own linear planes where that group changed, B's where
 // not; an unchanged group of scale 2 recomputed from B's scale 1 has the very bits B stored) — and scale 3 follows by
 // shuffles inside the tile, scales 4 and 5 from the 4 x 32 pixels of scale 3 in LDS: one trip to memory, one barrier.  The
 // sums run in sparse_down_body's order ((a + b) + c) + d over rows 2y, 2y+1 and columns 2x, 2x+1.
@@ -636,9 +636,13 @@ __device__ __forceinline__ void sparse_down1_body(const SparseParams &P, const i
 // them before the first is used.
 template <int U>
 __device__ __forceinline__ void sparse_down_tiles_body(const SparseParams &P, const int bx, const int gx) {
+    // Four waves per block, two tiles per wave (until late in round 4: eight waves, a tile each — a block that needs eight free wave
+    // slots of one CU at once is never placed while a kernel of one- or four-wave blocks keeps the chip full: beside the H pass of
+    // scale 0 this kernel took 211 us instead of 93, beside the V pass 627)
+    constexpr int TPW = 2;
     __shared__ float s_v3[U][3][4][32];
     const Geom &G = P.G;
-    const int t = threadIdx.x, lane = t & 63, tx = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int ly = lane >> 3, lx = lane & 7;
     const int total = P.item_count[3 * kColBuckets] / 3;
     const int NG3 = G.sh[3] >> 2;
@@ -658,27 +662,34 @@ __device__ __forceinline__ void sparse_down_tiles_body(const SparseParams &P, co
             sl2[u] = M->gslot[P.S.goff[2] + (y2 >> 2)];
         }
         // ---- scale 2: pixel (8 ty + ly, 8 tx + lx) from rows 2y, 2y+1 of scale 1 (one group: 4 ty + ly / 2) ----
-        float2 a[U][3], b[U][3];
+        float2 a[U][TPW][3], b[U][TPW][3];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const float *mine = P.store + (size_t)item_k(it[u]) * P.S.cand_stride;
-            const int gp = (8 * item_g(it[u]) + ly) >> 1, rp = (ly & 1) * 2, x2 = 8 * tx + lx;
+            const int gp = (8 * item_g(it[u]) + ly) >> 1, rp = (ly & 1) * 2;
             const float *grp = sl[u] >= 0 ? mine + P.S.off_lin[1] + (size_t)sl[u] * 12 * Wp : basep + P.S.off_lin[1] + (size_t)gp * 12 * Wp;
-            const float *q0 = grp + (size_t)((2 * x2) >> 2) * 16 + rp * 4 + ((2 * x2) & 3);
 #pragma unroll
-            for (int c = 0; c < 3; c++) { a[u][c] = *reinterpret_cast<const float2 *>(q0 + (size_t)c * 4 * Wp); b[u][c] = *reinterpret_cast<const float2 *>(q0 + (size_t)c * 4 * Wp + 4); }
+            for (int i = 0; i < TPW; i++) {
+                const int x2 = 8 * (TPW * w + i) + lx;
+                const float *q0 = grp + (size_t)((2 * x2) >> 2) * 16 + rp * 4 + ((2 * x2) & 3);
+#pragma unroll
+                for (int c = 0; c < 3; c++) { a[u][i][c] = *reinterpret_cast<const float2 *>(q0 + (size_t)c * 4 * Wp); b[u][i][c] = *reinterpret_cast<const float2 *>(q0 + (size_t)c * 4 * Wp + 4); }
+            }
         }
         __syncthreads(); // (the block's last read of s_v3 for the groups before)
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const bool live = g0 + u < total;
             float *mine = P.store + (size_t)item_k(it[u]) * P.S.cand_stride;
-            const int y2 = 8 * item_g(it[u]) + ly, x2 = 8 * tx + lx;
+            const int y2 = 8 * item_g(it[u]) + ly;
+#pragma unroll
+            for (int i = 0; i < TPW; i++) {
+            const int tx = TPW * w + i, x2 = 8 * tx + lx;
             float v2[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 float sum = 0.0f;
-                sum += a[u][c].x; sum += a[u][c].y; sum += b[u][c].x; sum += b[u][c].y;
+                sum += a[u][i][c].x; sum += a[u][i][c].y; sum += b[u][i][c].x; sum += b[u][i][c].y;
                 v2[c] = sum * 0.25f;
             }
             if (live && sl2[u] >= 0) { // (uniform over each half of the wave: rows 0-3 and 4-7 of the tile are the two groups of scale 2)
@@ -694,6 +705,7 @@ __device__ __forceinline__ void sparse_down_tiles_body(const SparseParams &P, co
                 float sum = 0.0f;
                 sum += v2[c]; sum += b1; sum += c1; sum += d1;
                 if (((ly | lx) & 1) == 0) s_v3[u][c][ly >> 1][4 * tx + (lx >> 1)] = sum * 0.25f;
+            }
             }
         }
         __syncthreads();
@@ -712,7 +724,7 @@ __device__ __forceinline__ void sparse_down_tiles_body(const SparseParams &P, co
                 float *orr = mine + P.S.off_xybR[3] + (size_t)j3 * 12 * Ws + (size_t)x * 4 + r;
                 oc[0] = X; oc[(size_t)4 * Ws] = Y; oc[(size_t)8 * Ws] = B;
                 orr[0] = X; orr[(size_t)4 * Ws] = Y; orr[(size_t)8 * Ws] = B;
-            } else if (t < 192) { // scale 4: rows 2 ty, 2 ty + 1 x 16 pixels
+            } else if (t < 192) { // scale 4: rows 2 ty, 2 ty + 1 x 16 pixels, then (below) the rows under an unchanged neighbour
                 const int i = t - 128;
                 if (G.nscales > 4 && i < 32) {
                     const int a4 = i >> 4, x = i & 15, Ws = G.sw[4];
@@ -761,20 +773,21 @@ __device__ __forceinline__ void sparse_down_tiles_body(const SparseParams &P, co
                     oc[0] = X; oc[(size_t)4 * Ws] = Y; oc[(size_t)8 * Ws] = B;
                     orr[0] = X; orr[(size_t)4 * Ws] = Y; orr[(size_t)8 * Ws] = B;
                 }
-            } else if (t < 320) { // scale 4: the two rows under the unchanged other half of the group are B's
+            }
+            if (t >= 128 && t < 192) { // scale 4 (the wave that took its pixels): the two rows under the unchanged other half of the group are B's
                 const int sib = ty ^ 1;
                 if (G.nscales > 4 && sib < NG3 && M->gslot[P.S.goff[3] + sib] < 0) {
                     const int Ws = G.sw[4], g4 = ty >> 1;
                     const int j4 = M->gslot[P.S.goff[4] + g4];
                     const float *bc = basep + P.S.off_xybC[4] + (size_t)g4 * 12 * Ws, *br = basep + P.S.off_xybR[4] + (size_t)g4 * 12 * Ws;
                     float *oc = mine + P.S.off_xybC[4] + (size_t)j4 * 12 * Ws, *orr = mine + P.S.off_xybR[4] + (size_t)j4 * 12 * Ws;
-                    for (int i = t - 256; i < 3 * 2 * Ws; i += 64) { // (channel, row of the pair, column)
+                    for (int i = t - 128; i < 3 * 2 * Ws; i += 64) { // (channel, row of the pair, column)
                         const int c = i / (2 * Ws), rem = i % (2 * Ws), r = ((2 * sib) & 3) + rem / Ws, x = rem % Ws;
                         const size_t ic = (size_t)c * 4 * Ws + (size_t)(x >> 2) * 16 + r * 4 + (x & 3), ir = (size_t)c * 4 * Ws + (size_t)x * 4 + r;
                         oc[ic] = bc[ic]; orr[ir] = br[ir];
                     }
                 }
-            } else if (t < 384) { // scale 5: the group's first changed group of scale 3 brings B's rows under the unchanged ones
+            } else if (t >= 192) { // scale 5 (the wave that took its pixels): the group's first changed group of scale 3 brings B's rows under the unchanged ones
                 if (G.nscales > 5) {
                     const int g5 = ty >> 2, lo = 4 * g5, hi = min(lo + 4, NG3);
                     bool first = true;
@@ -787,7 +800,7 @@ __device__ __forceinline__ void sparse_down_tiles_body(const SparseParams &P, co
                         for (int q = lo; q < hi; q++) {
                             if (q == ty || M->gslot[P.S.goff[3] + q] >= 0) continue;
                             const int r = q & 3;
-                            for (int i = t - 320; i < 3 * Ws; i += 64) {
+                            for (int i = t - 192; i < 3 * Ws; i += 64) {
                                 const int c = i / Ws, x = i % Ws;
                                 const size_t ic = (size_t)c * 4 * Ws + (size_t)(x >> 2) * 16 + r * 4 + (x & 3), ir = (size_t)c * 4 * Ws + (size_t)x * 4 + r;
                                 oc[ic] = bc[ic]; orr[ir] = br[ir];
@@ -1356,7 +1369,7 @@ __global__ __launch_bounds__(256) void k_dither_first_lab(SparseParams P) { dith
 __global__ __launch_bounds__(1024) void k_dither_diff(SparseParams P) { dither_diff_body(P); }
 __global__ __launch_bounds__(256) void k_sparse_down(SparseParams P, int only_scale) { sparse_down_body(P, only_scale, (int)blockIdx.x); }
 __global__ __launch_bounds__(256) void k_sparse_down1(SparseParams P) { sparse_down1_body(P, (int)blockIdx.x, (int)gridDim.x); }
-__global__ __launch_bounds__(512) void k_sparse_down_tiles(SparseParams P) { sparse_down_tiles_body<SNES_DOWN_TILES_U>(P, (int)blockIdx.x, (int)gridDim.x); }
+__global__ __launch_bounds__(256) void k_sparse_down_tiles(SparseParams P) { sparse_down_tiles_body<SNES_DOWN_TILES_U>(P, (int)blockIdx.x, (int)gridDim.x); }
 __global__ __launch_bounds__(256) void k_base_down(SparseParams P) { base_down_body(P); }
 __global__ __launch_bounds__(64) void k_sparse_h(SparseParams P) { sparse_h_body(P); }
 __global__ __launch_bounds__(256, 1) void k_sparse_v_base(SparseParams P) { sparse_v_base_body(P); }

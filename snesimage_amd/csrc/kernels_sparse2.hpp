@@ -733,6 +733,8 @@ __global__ __launch_bounds__(64) void k_sparse_h2q(SparseParams P) { sparse_h2q_
 __global__ __launch_bounds__(64) void k_sparse_h2q_base(SparseParams P) { sparse_h2q_dispatch<true>(P, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x); } // B: a single image is a short list
 __global__ __launch_bounds__(64) void k_sparse_h2_base(SparseParams P) { sparse_h2_dispatch<true>(P, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x); }
 __global__ __launch_bounds__(256, 5) void k_sparse_v2(SparseParams P) { if ((int)blockIdx.y < P.G.nscales && P.G.sw[blockIdx.y] >= 64) sparse_v2_body<false>(P, (int)blockIdx.y, (int)blockIdx.x); }
+// the wide scales from s0 on (the launch that follows the other scales' H pass when scale 0, whose H pass went ahead, runs beside it)
+__global__ __launch_bounds__(256, 5) void k_sparse_v2_from(SparseParams P, int s0) { const int s = s0 + (int)blockIdx.y; if (s < P.G.nscales && P.G.sw[s] >= 64) sparse_v2_body<false>(P, s, (int)blockIdx.x); }
 // B: the wide scales in this body (grid.y = scale), the narrow ones in the general one (grid.y = scale - s_first), two launches:
 // one kernel holding both bodies would take the larger register allocation for every block
 // B, split: grid.x = 64-column block (W / 64 of the widest scale), grid.y = channel, grid.z = scale; 128 threads
