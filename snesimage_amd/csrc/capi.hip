@@ -333,8 +333,8 @@ int32_t run_prep(snesimage_ctx *c, int mode, int sp, int si) {
     P.labpx = c->d_labpx; P.pal_lab = c->d_pal_lab;
     P.W = (int)c->W; P.H = (int)c->H; P.sub_size = (int)c->sub_size; P.ncol = c->ncol; P.mode = mode; P.sp = sp; P.si = si; P.perceptual = c->perceptual ? 1 : 0;
     c->sp.counters_cleared = false;
-    if (mode == 2 && c->sp.plist_count) { // B's item counters (lane index nlanes) and the contested-pixel count sit side by side
-        P.zero = c->sp.item_count + (size_t)c->nlanes * kItemLists; P.nzero = kItemLists + 1; c->sp.counters_cleared = true;
+    if (mode == 2 && c->sp.plist_count) { // the contested-pixel count of the slot
+        P.zero = c->sp.plist_count; P.nzero = 1; c->sp.counters_cleared = true; // (B's own item counters are never cleared: sparse_alloc)
     }
     hipLaunchKernelGGL(k_prep, dim3((unsigned)((c->npx + 255) / 256)), dim3(256), 0, c->stream, P);
     HIPCHK(hipGetLastError());
@@ -449,6 +449,8 @@ int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double
 
 // ---- row-sparse path ------------------------------------------------------------------------------------
 // grow-only: `need` = candidates per lane of the launch groups to come
+SparseParams sparse_params(snesimage_ctx *c, uint32_t lane);
+
 int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
     auto &sp = c->sp;
     if (sp.cap >= need) return SNES_OK;
@@ -524,8 +526,16 @@ int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
             if (!ah.ev) HIPCHK(hipEventCreateWithFlags(&ah.ev, hipEventDisableTiming));
         }
     }
-    HIPCHK(hipStreamSynchronize(c->stream)); // the clears above precede whatever the lanes and B's stream launch next
     sp.cap = need; sp.plist_valid = false;
+    { // B's work items — every group of every scale, from column 0 — and its group tables depend on the geometry alone: published
+      // once, here, and left alone (until late in round 4 every call cleared and republished them: a 1,024-thread block of its own,
+      // 11-14 us at the head of B's chain, which is what a short call waits for)
+        SparseParams P = sparse_params(c, c->nlanes);
+        P.is_base = 1; P.ncand = 1; P.k0 = P.base;
+        hipLaunchKernelGGL(k_sparse_scan, dim3(1), dim3(1024), 0, c->stream, P);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(c->stream)); // the clears above precede whatever the lanes and B's stream launch next
     return SNES_OK;
 }
 
@@ -557,7 +567,7 @@ int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si, uint32_t n_cand) 
     auto &sp = c->sp;
     const Geom &G = c->G;
     if (!sp.plist_valid) {
-        if (!sp.counters_cleared) HIPCHK(hipMemsetAsync(sp.item_count + (size_t)c->nlanes * kItemLists, 0, sizeof(int) * (kItemLists + 1), c->stream)); // normally k_prep did it
+        if (!sp.counters_cleared) HIPCHK(hipMemsetAsync(sp.plist_count, 0, sizeof(int), c->stream)); // normally k_prep did it
         sp.counters_cleared = false; // about to be used
         const unsigned long long *win_pack = c->d_pack;
         if (c->dither) {
@@ -611,7 +621,7 @@ int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si, uint32_t n_cand) 
         if (!down_with_sweeps) hipLaunchKernelGGL(k_base_down, dim3((unsigned)((G.W / 32) * ((G.H + 31) / 32))), dim3(256), 0, c->stream, P); // B: every row of every scale
         if (sp.side) { HIPCHK(hipEventRecord(sp.ev_base_in, c->stream)); HIPCHK(hipStreamWaitEvent(bs, sp.ev_base_in, 0)); }
         if (down_with_sweeps) hipLaunchKernelGGL(k_base_down, dim3((unsigned)((G.W / 32) * ((G.H + 31) / 32))), dim3(256), 0, bs, P);
-        hipLaunchKernelGGL(k_sparse_scan, dim3(1), dim3(1024), 0, bs, P); // B's work items (every group, from column 0): only B's own sweeps read them
+        // (B's work items — every group, from column 0 — are in place since sparse_alloc)
         // wide scales: B rows start at column 0 (list s*kColBuckets) and leave the per-block H checkpoints and the scale-0 XYB plane
         if (sp.h2q_max > 0) hipLaunchKernelGGL(k_sparse_h2q_base, dim3((unsigned)((G.sh[0] / 4 * 3 + 3) / 4), (unsigned)(P.s_first * kColBuckets)), dim3(64), h2_lds(c), bs, P);
         else hipLaunchKernelGGL(k_sparse_h2_base, dim3((unsigned)((G.sh[0] / 4 * 3 + 15) / 16), (unsigned)(P.s_first * kColBuckets)), dim3(64), h2_lds(c), bs, P);
