@@ -486,6 +486,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_candidate": ALGO_BYTES_PER_CANDIDATE, "candidates_per_launch": per_launch,
                          "avg_launch_ms": dom_ms,
+                         "kernel_note": ("launch groups of 1,024 candidates and more run on two streams: this launch of k_sparse_v2 is scale 0 of the V pass "
+                                         "(three quarters of it) with the downscale, the H pass of scales 1-2, the narrow scales and k_sparse_v2_from (scales 1-2) "
+                                         "resident beside it; its duration is what it takes in that company (alone on the chip: profiles/r4_wave_cycles_4096.txt)")
+                                        if sparse and dom == vname and per_launch >= int(os.environ.get("SNES_H0_MIN", "1024")) > 0 and os.environ.get("SNES_V0_ASIDE", "1") != "0" else None,
                          "pipeline_achieved": value / world * ALGO_BYTES_PER_CANDIDATE / 1e9,
                          "pipeline_frac": value / world * ALGO_BYTES_PER_CANDIDATE / 1e9 / HBM_PEAK_GBS,
                          "pipeline_frac_dense_ssimulacra2_bytes": value / world * SSIM2_DENSE_BYTES_PER_CANDIDATE / 1e9 / HBM_PEAK_GBS},

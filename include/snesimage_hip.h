@@ -222,8 +222,9 @@ void snesimage_debug_fail_alloc(int32_t n);
  *   ms3[0] = the whole launch group (all kernels that score one chunk of candidates);
  *   ms3[1] = the H pass: k_sparse_h2 + k_sparse_h (wide and narrow scales) on the group-sparse path, k_hpass* at scale 0 otherwise;
  *   ms3[2] = the V pass, the dominant kernel: k_sparse_v2 alone (one launch, the scales at least 64 wide; the wait for
- *            B's checkpoints and k_sparse_order come before the opening event) on the group-sparse path, k_vpass* at
- *            scale 0 otherwise;
+ *            B's checkpoints and k_sparse_order come before the opening event) on the group-sparse path — for launch groups
+ *            of 1,024 candidates and more, which run on two streams, the launch of scale 0 (three quarters of the V pass)
+ *            on its stream, with the other stream's kernels resident beside it — k_vpass* at scale 0 otherwise;
  * plus the number of launch groups and the candidates they scored since timing was enabled.
  * on = 1: all three brackets — six event records per launch group, each a ~4 us bubble in the stream (25 us per group: 1.5 % of a
  * 4,096-candidate group, 9 % of a 64-candidate one; profiles/r4_timing_cost.py).  on = 2: the V pass's bracket only (ms3[0] and

@@ -84,6 +84,9 @@ __global__ __launch_bounds__(64) void kb_sparse_h(const BatchArgs *__restrict__ 
 __global__ __launch_bounds__(64) void kb_sparse_h2(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_h2_dispatch<false>(a.Pc, bb.y, bb.x, (int)gridDim.x); }
 __global__ __launch_bounds__(64) void kb_sparse_h2_base(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_h2_dispatch<true>(a.Pb, bb.y, bb.x, (int)gridDim.x); }
 // the quad-per-row H pass (a third of the chain per column quad for four times the waves): short windows, whose stages are latency
+// (the lists from list0 on / the wide scales from s0 on: a window's members on two streams, as score_list does for long lists)
+__global__ __launch_bounds__(64) void kb_sparse_h2_lists(const BatchArgs *__restrict__ A, const int *__restrict__ dead, int list0) { SNES_BATCH_XCD; sparse_h2_dispatch<false>(a.Pc, list0 + bb.y, bb.x, (int)gridDim.x); }
+__global__ __launch_bounds__(256, 5) void kb_sparse_v2_scales(const BatchArgs *__restrict__ A, const int *__restrict__ dead, int s0) { SNES_BATCH_XCD; const int s = s0 + bb.y; if (s < a.Pc.G.nscales && a.Pc.G.sw[s] >= 64) sparse_v2_body<false>(a.Pc, s, bb.x); }
 __global__ __launch_bounds__(64) void kb_sparse_h2q(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_h2q_dispatch<false>(a.Pc, bb.y, bb.x, (int)gridDim.x); }
 __global__ __launch_bounds__(64) void kb_sparse_h2q_base(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; sparse_h2q_dispatch<true>(a.Pb, bb.y, bb.x, (int)gridDim.x); }
 __global__ __launch_bounds__(256, 5) void kb_sparse_v2(const BatchArgs *__restrict__ A, const int *__restrict__ dead) { SNES_BATCH_XCD; if (bb.y < a.Pc.G.nscales && a.Pc.G.sw[bb.y] >= 64) sparse_v2_body<false>(a.Pc, bb.y, bb.x); }
