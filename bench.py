@@ -495,6 +495,11 @@ def main():
                          "pipeline_frac_dense_ssimulacra2_bytes": value / world * SSIM2_DENSE_BYTES_PER_CANDIDATE / 1e9 / HBM_PEAK_GBS},
         }
         out["valu_roofline"] = valu
+        try:  # what the context holds in HBM (candidate storage is dense per launch lane, allocated for the lanes a list is dealt to)
+            free_b, total_b = torch.cuda.mem_get_info()
+            out["hbm_in_use_gb"] = round((total_b - free_b) / 2 ** 30, 2)
+        except Exception:
+            pass
         if stale_pmc:
             out["stale_pmc"] = stale_pmc
         out["library"] = lib_version()

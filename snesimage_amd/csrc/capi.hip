@@ -139,6 +139,7 @@ struct snesimage_ctx {
     // takes the winner's map instead of dithering the image again (lib.rs:237 re-runs optimize() on the winner's palette)
     uint8_t *d_bestmap = nullptr, *d_bestmaps_all = nullptr; BestRec *d_bestrec = nullptr, *d_bestrecs_all = nullptr; int *d_skip = nullptr;
     uint4 *d_rplist = nullptr; int *d_rcount = nullptr; // contested pixels for the perceptual remap-only entry point
+    float *d_rtab = nullptr, *d_rlab = nullptr; uint32_t rtab_cap = 0; // the remap-only entry point's candidate tables (it needs none of the scoring workspace)
     bool map_pending = false; // without dither the optimize() that ends a step (lib.rs:237) is deferred until something reads palette_map
     bool best_valid = false, map_synced = false; // records belong to the list being committed; d_map is optimize() of the current palette
     // Additional launch lanes: chunk i of a candidate list runs on lane i % nlanes (lane 0 = the context's stream and the
@@ -167,7 +168,7 @@ struct snesimage_ctx {
         bool vsplit = true; // B's wide V sweep with recurrences and maps on two waves (k_sparse_v2_base_split; SNES_VSPLIT=0: one wave does both)
         uint32_t scan4_max = 2048; // longest list whose scan deals a candidate's contested pixels to four waves (SNES_SCAN4_MAX; 0 = never)
         uint32_t hgrid = 8192; // most blocks per scale of k_sparse_h (grid-stride beyond)
-        bool enabled = false, side = true; uint32_t min_n = 1; uint32_t cap = 0; // min_n: shortest list that takes the group-sparse path (SNES_SPARSE_MIN; until round 4: 64 — a channel sweep's 32 candidates, or a rank's share of a 64-candidate call, went the dense way: 0.35 ms against 0.27, 1.7 ms with --perceptual-palettes) // cap = candidates per lane the arrays were sized for
+        bool enabled = false, side = true; uint32_t min_n = 1; uint32_t cap = 0, lanes = 0; // min_n: shortest list that takes the group-sparse path (SNES_SPARSE_MIN; until round 4: 64 — a channel sweep's 32 candidates, or a rank's share of a 64-candidate call, went the dense way: 0.35 ms against 0.27, 1.7 ms with --perceptual-palettes) // cap = candidates per lane the arrays were sized for
         SparseGeom S{};
         float *store = nullptr, *cand_tab = nullptr, *cand_lab = nullptr, *ckf = nullptr, *ckh = nullptr; long long zeros_off = 0; uint32_t *bitmap = nullptr; double *cka = nullptr, *part = nullptr;
         CandMeta *meta = nullptr; unsigned int *items = nullptr; int *item_count = nullptr; long long item_stride = 0; int *order = nullptr, *first = nullptr;
@@ -451,13 +452,18 @@ int32_t score_chunk(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t nc, double
 // grow-only: `need` = candidates per lane of the launch groups to come
 SparseParams sparse_params(snesimage_ctx *c, uint32_t lane);
 
-int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
+// `lanes` = launch lanes that get candidate storage: a list that fits one launch group runs on lane 0 alone (score_list), so the
+// other lanes' planes — 4.45 MB per candidate each — are allocated by the first list that is dealt to them, not before
+int32_t sparse_alloc(snesimage_ctx *c, uint32_t need, uint32_t lanes = 1) {
     auto &sp = c->sp;
-    if (sp.cap >= need) return SNES_OK;
+    if (lanes > c->nlanes) lanes = c->nlanes;
+    if (sp.cap >= need && sp.lanes >= lanes) return SNES_OK;
+    if (need < sp.cap) need = sp.cap;
+    if (lanes < sp.lanes) lanes = sp.lanes;
     HIPCHK(hipStreamSynchronize(c->stream));
     for (auto &L : c->extra) HIPCHK(hipStreamSynchronize(L.stream));
     if (sp.base_stream) HIPCHK(hipStreamSynchronize(sp.base_stream));
-    sp.cap = 0; sp.plist_valid = false; // released below: a failed grow must not leave the old capacity behind
+    sp.cap = 0; sp.lanes = 0; sp.plist_valid = false; // released below: a failed grow must not leave the old capacity behind
     dfree(sp.store); dfree(sp.cand_tab); dfree(sp.ckf); dfree(sp.cka); dfree(sp.part); dfree(sp.meta); dfree(sp.items); dfree(sp.item_count); dfree(sp.plist); sp.plist_count = nullptr;
     const Geom &G = c->G;
     SparseGeom &S = sp.S;
@@ -474,7 +480,7 @@ int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
         S.goff[s] = go; go += G.sh[s] / 4;
     }
     S.cand_stride = off;
-    const size_t ncap = (size_t)c->nlanes * need + 1; // + the base image B
+    const size_t ncap = (size_t)lanes * need + 1; // + the base image B
     sp.item_stride = (long long)need * (G.sh[0] / 4) * 3;
     HIPCHK(dmalloc(&sp.store, sizeof(float) * (size_t)S.cand_stride * ncap));
     HIPCHK(dmalloc(&sp.cand_tab, sizeof(float) * 8 * ncap));
@@ -510,8 +516,8 @@ int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
     HIPCHK(dmalloc(&sp.plist, sizeof(uint4) * c->npx));
     if (c->dither) {
         dfree(sp.dmaps); dfree(sp.dmapsC4); dfree(sp.bmap); dfree(sp.bmapC4); dfree(sp.bcand); dfree(sp.dpack); dfree(sp.ckd);
-        HIPCHK(dmalloc(&sp.dmaps, c->npx * (size_t)need * c->nlanes));
-        HIPCHK(dmalloc(&sp.dmapsC4, c->npx * (size_t)need * c->nlanes));
+        HIPCHK(dmalloc(&sp.dmaps, c->npx * (size_t)need * lanes));
+        HIPCHK(dmalloc(&sp.dmapsC4, c->npx * (size_t)need * lanes));
         HIPCHK(dmalloc(&sp.bmap, c->npx)); HIPCHK(dmalloc(&sp.bmapC4, c->npx)); HIPCHK(dmalloc(&sp.bcand, 64));
         HIPCHK(dmalloc(&sp.dpack, sizeof(unsigned long long) * c->npx));
         HIPCHK(dmalloc(&sp.ckd, sizeof(double) * 3 * c->W * (c->H / 4 + 1)));
@@ -526,7 +532,7 @@ int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
             if (!ah.ev) HIPCHK(hipEventCreateWithFlags(&ah.ev, hipEventDisableTiming));
         }
     }
-    sp.cap = need; sp.plist_valid = false;
+    sp.cap = need; sp.lanes = lanes; sp.plist_valid = false;
     { // B's work items — every group of every scale, from column 0 — and its group tables depend on the geometry alone: published
       // once, here, and left alone (until late in round 4 every call cleared and republished them: a 1,024-thread block of its own,
       // 11-14 us at the head of B's chain, which is what a short call waits for)
@@ -542,7 +548,7 @@ int32_t sparse_alloc(snesimage_ctx *c, uint32_t need) {
 SparseParams sparse_params(snesimage_ctx *c, uint32_t lane) {
     auto &sp = c->sp;
     SparseParams P{};
-    P.G = c->G; P.S = sp.S; P.K = c->K; P.ncol = c->ncol; P.base = (int)(c->nlanes * sp.cap);
+    P.G = c->G; P.S = sp.S; P.K = c->K; P.ncol = c->ncol; P.base = (int)(sp.lanes * sp.cap);
     P.pack = c->d_pack; P.packC4 = c->d_packC4; P.packR4 = c->d_packR4; P.plist = sp.plist; P.plist_count = sp.plist_count;
     P.pal_lin = c->d_pal_lin; P.pal_xyb = c->d_pal_xyb; P.cand_tab = sp.cand_tab;
     P.perceptual = c->perceptual ? 1 : 0; P.labpx = c->d_labpx; P.cand_lab = sp.cand_lab; P.bitmap = sp.bitmap;
@@ -586,14 +592,14 @@ int32_t sparse_base_pass(snesimage_ctx *c, int sp_idx, int si, uint32_t n_cand) 
             }
             ah.have = false;
             HIPCHK(hipMemcpyAsync(sp.bcand, c->d_colors + 3 * (size_t)(sp_idx * (int)c->sub_size + (int)j0), 3, hipMemcpyDeviceToDevice, c->stream));
-            float *btab = sp.cand_tab + 8 * (size_t)(c->nlanes * sp.cap);
+            float *btab = sp.cand_tab + 8 * (size_t)(sp.lanes * sp.cap);
             hipLaunchKernelGGL(k_candidate_tables, dim3(1), dim3(64), 0, c->stream, sp.bcand, 1, c->d_eotf, btab);
             DitherParams Dp{};
             Dp.orig = c->d_orig; Dp.tile_pal = c->d_tile_pal; Dp.pal_rgb8 = c->d_pal_rgb8; Dp.cand_tab = btab; Dp.maps = sp.bmap; Dp.mapsC4 = sp.bmapC4;
             Dp.W = (int)c->W; Dp.H = (int)c->H; Dp.sub_size = (int)c->sub_size; Dp.ncol = c->ncol; Dp.slot_ci = sp.slot_ci;
             Dp.rec_pack = sp.dpack; Dp.ck_out = sp.ckd; Dp.excl_sub = sp_idx; Dp.excl_si = si; Dp.excl_j0 = (int)j0; Dp.skip = b_done;
             if (c->perceptual) { // CIEDE2000: the stand-in's Lab in B's row of the candidates' table, the record in distance bits, the targets' Lab beside it
-                float *blab = sp.cand_lab + 3 * (size_t)(c->nlanes * sp.cap);
+                float *blab = sp.cand_lab + 3 * (size_t)(sp.lanes * sp.cap);
                 hipLaunchKernelGGL(k_candidate_lab, dim3(1), dim3(64), 0, c->stream, btab, 1, c->d_lab_eotf, blab);
                 Dp.pal_lab = c->d_pal_lab; Dp.cand_lab = blab; Dp.lab_eotf = c->d_lab_eotf; Dp.perceptual = 1; Dp.rec_lab = sp.rec_lab;
                 if (c->dither4) hipLaunchKernelGGL((k_dither4_lab<1>), dim3(1), dim3(512), 0, c->stream, Dp); else hipLaunchKernelGGL((k_dither<true, 0, 1>), dim3(1), dim3(128), 0, c->stream, Dp);
@@ -824,7 +830,7 @@ int32_t score_list(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t n, double *
     const uint32_t nchunks = (n + chunk - 1) / chunk;
     const uint32_t nl = nchunks < c->nlanes ? nchunks : c->nlanes;
     if (sparse) {
-        CHECK(sparse_alloc(c, chunk));
+        CHECK(sparse_alloc(c, chunk, nl));
         if (c->dither && (c->sp.base_sp != sp || c->sp.base_si != si)) c->sp.plist_valid = false;
         CHECK(sparse_base_pass(c, sp, si, n));
         c->sp.base_sp = sp; c->sp.base_si = si;
@@ -1122,7 +1128,7 @@ void snesimage_destroy(snesimage_ctx *c) {
     dfree(c->d_packC4); dfree(c->d_packR4); dfree(c->d_subC4); dfree(c->d_subR4); dfree(c->d_mapsC4); dfree(c->d_mapsR4); dfree(c->d_img1C4); dfree(c->d_mu1R4); dfree(c->d_sd1R4); dfree(c->d_r1); dfree(c->d_r1R4); dfree(c->d_a1); dfree(c->d_a1R4);
     dfree(c->d_orig); dfree(c->d_tile_pal); dfree(c->d_colors); dfree(c->d_map); dfree(c->d_pack); dfree(c->d_packT); dfree(c->d_eotf); dfree(c->d_lab_eotf);
     dfree(c->d_pal_rgb8); dfree(c->d_pal_lin); dfree(c->d_pal_xyb); dfree(c->d_pal_lab); dfree(c->d_lin0); dfree(c->d_img1); dfree(c->d_img1T); dfree(c->d_mu1); dfree(c->d_sd1);
-    dfree(c->d_bestmaps_all); dfree(c->d_bestrecs_all); dfree(c->d_skip); dfree(c->d_rplist); dfree(c->d_rcount); dfree(c->d_tile_cost); dfree(c->d_tile_any); dfree(c->d_tile_moved);
+    dfree(c->d_bestmaps_all); dfree(c->d_bestrecs_all); dfree(c->d_skip); dfree(c->d_rplist); dfree(c->d_rcount); dfree(c->d_rtab); dfree(c->d_rlab); dfree(c->d_tile_cost); dfree(c->d_tile_any); dfree(c->d_tile_moved);
     dfree(c->d_labpx); dfree(c->d_labpxT); dfree(c->d_work); dfree(c->d_cand_tab); dfree(c->d_cand_lab); dfree(c->d_part); dfree(c->d_maps); dfree(c->d_mapsT);
     dfree(c->d_cand); dfree(c->d_cand_sel); dfree(c->d_errs); dfree(c->d_errs_sel); dfree(c->d_inc_err); dfree(c->d_last); dfree(c->d_scratch_err); dfree(c->d_dummy_cand);
     for (auto &L : c->extra) { if (L.stream) (void)hipStreamSynchronize(L.stream); dfree(L.d_mapsC4); dfree(L.d_mapsR4); dfree(L.d_work); dfree(L.d_cand_tab); dfree(L.d_cand_lab); dfree(L.d_part); dfree(L.d_maps); dfree(L.d_mapsT); if (L.done) (void)hipEventDestroy(L.done); if (L.stream) (void)hipStreamDestroy(L.stream); }
@@ -1155,7 +1161,7 @@ int32_t snesimage_set_chunk(snesimage_ctx *c, uint32_t chunk) {
     CHECK(set_device(c));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->chunk = chunk;
-    c->sp.cap = 0; c->sp.plist_valid = false; // storage indices of the row-sparse path depend on the chunk size
+    c->sp.cap = 0; c->sp.lanes = 0; c->sp.plist_valid = false; // storage indices of the row-sparse path depend on the chunk size
     return SNES_OK;
 }
 
@@ -1205,7 +1211,14 @@ int32_t snesimage_remap_candidates_device(snesimage_ctx *c, uint32_t palette, ui
     if (n == 0) return SNES_OK;
     CHECK(set_device(c));
     const uint32_t chunk = n < c->chunk ? n : c->chunk;
-    CHECK(alloc_workspace(c, chunk));
+    CHECK(alloc_workspace(c, 1)); // (lanes, d_skip; the maps go straight to the caller's buffer: no per-candidate planes — until round 4 this
+    // call sized the dense scoring workspace, 4.5 MB per candidate and lane, for its chunk and left it with the context)
+    if (c->rtab_cap < chunk) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->rtab_cap = 0; dfree(c->d_rtab); dfree(c->d_rlab);
+        HIPCHK(dmalloc(&c->d_rtab, sizeof(float) * 8 * (size_t)chunk)); HIPCHK(dmalloc(&c->d_rlab, sizeof(float) * 3 * (size_t)chunk));
+        c->rtab_cap = chunk;
+    }
     CHECK(ensure_tables(c));
     if (c->perceptual) CHECK(ensure_source(c));
     CHECK(prep_for_slot(c, (int)palette, (int)index));
@@ -1214,17 +1227,17 @@ int32_t snesimage_remap_candidates_device(snesimage_ctx *c, uint32_t palette, ui
         const uint32_t nc = (n - c0 < chunk) ? (n - c0) : chunk;
         const uint8_t *rgb5 = d_rgb5 + 3 * (size_t)c0;
         uint8_t *maps = d_maps_out + (size_t)c0 * c->npx;
-        hipLaunchKernelGGL(k_candidate_tables, dim3((nc + 63) / 64), dim3(64), 0, c->stream, rgb5, (int)nc, c->d_eotf, c->d_cand_tab);
-        if (c->perceptual) hipLaunchKernelGGL(k_candidate_lab, dim3((nc + 63) / 64), dim3(64), 0, c->stream, c->d_cand_tab, (int)nc, c->d_lab_eotf, c->d_cand_lab);
+        hipLaunchKernelGGL(k_candidate_tables, dim3((nc + 63) / 64), dim3(64), 0, c->stream, rgb5, (int)nc, c->d_eotf, c->d_rtab);
+        if (c->perceptual) hipLaunchKernelGGL(k_candidate_lab, dim3((nc + 63) / 64), dim3(64), 0, c->stream, c->d_rtab, (int)nc, c->d_lab_eotf, c->d_rlab);
         if (c->dither) {
-            hipLaunchKernelGGL(k_candidate_slot, dim3((nc + 63) / 64), dim3(64), 0, c->stream, c->d_cand_tab, (int)nc, slot_ci);
+            hipLaunchKernelGGL(k_candidate_slot, dim3((nc + 63) / 64), dim3(64), 0, c->stream, c->d_rtab, (int)nc, slot_ci);
             DitherParams Dp{};
-            Dp.orig = c->d_orig; Dp.tile_pal = c->d_tile_pal; Dp.pal_rgb8 = c->d_pal_rgb8; Dp.pal_lab = c->d_pal_lab; Dp.cand_tab = c->d_cand_tab; Dp.cand_lab = c->d_cand_lab;
+            Dp.orig = c->d_orig; Dp.tile_pal = c->d_tile_pal; Dp.pal_rgb8 = c->d_pal_rgb8; Dp.pal_lab = c->d_pal_lab; Dp.cand_tab = c->d_rtab; Dp.cand_lab = c->d_rlab;
             Dp.lab_eotf = c->d_lab_eotf; Dp.maps = maps; Dp.mapsC4 = nullptr;
             Dp.W = (int)c->W; Dp.H = (int)c->H; Dp.sub_size = (int)c->sub_size; Dp.ncol = c->ncol; Dp.slot_ci = slot_ci; Dp.perceptual = c->perceptual ? 1 : 0;
             launch_dither(c, Dp, nc);
         } else {
-            MapsParams M{}; M.pack = c->d_pack; M.cand_tab = c->d_cand_tab; M.cand_lab = c->d_cand_lab; M.labpx = c->d_labpx; M.maps = maps;
+            MapsParams M{}; M.pack = c->d_pack; M.cand_tab = c->d_rtab; M.cand_lab = c->d_rlab; M.labpx = c->d_labpx; M.maps = maps;
             M.npx = (int)c->npx; M.ncol = c->ncol; M.sub_size = (int)c->sub_size; M.si = (int)index; M.ncand = (int)nc; M.perceptual = c->perceptual ? 1 : 0;
             const dim3 grid((unsigned)((c->npx / 4 + 255) / 256), (nc + kRemapCands - 1) / kRemapCands);
             if (c->perceptual) { // B's map for everyone, then the CIEDE2000 win tests over the slot's contested pixels only

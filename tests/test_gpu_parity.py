@@ -619,6 +619,37 @@ def test_sparse_path_equals_dense_path(S, O, seed, variant, perceptual, monkeypa
     sparse.close()
 
 
+def test_lane_storage_grows_with_the_lanes_in_use(S, monkeypatch):
+    """Candidate storage of the group-sparse path is allocated for the launch lanes a list is dealt to (sparse_alloc): a list that
+    fits one launch group leaves the second lane without planes; the first longer list grows the storage — same capacity per lane,
+    B's planes behind the last lane — and scores as the dense path does, as do the lists after it."""
+    from snesimage_amd.synth import synth_image
+    img = synth_image(0x5EED0003, 256, 256, 0)
+    monkeypatch.setenv("SNES_SPARSE", "0")
+    dense = S.OptimizedImage(img, 8, 15)
+    monkeypatch.setenv("SNES_SPARSE", "1")
+    monkeypatch.setenv("SNES_SPARSE_MIN", "1")
+    sparse = S.OptimizedImage(img, 8, 15)
+    dense.initialize_tiles()
+    dense.recalculate_palettes()
+    sparse.tile_palettes = dense.tile_palettes
+    sparse.palette = dense.palette
+    sparse.optimize()
+    dense.set_chunk(100)
+    sparse.set_chunk(100)
+    cand = S.random_candidates(0x5EED0003, 4 * 15 + 2, 250)
+    cand[0] = dense.palette[4 * 15 + 2]
+    for n in (100, 250, 60, 250, 100):  # one lane; two lanes (grows); one lane again on the grown storage; two; one
+        ed = dense.score_candidates(4, 2, cand[:n])
+        es = sparse.score_candidates(4, 2, cand[:n])
+        assert np.array_equal(ed, es), (n, float(np.max(np.abs(ed - es))))
+    e_d, b_d = dense.step(S.METHOD_RANDOM, 4, 2, 0, 11, 1, 250)
+    e_s, b_s = sparse.step(S.METHOD_RANDOM, 4, 2, 0, 11, 1, 250)
+    assert e_d == e_s and np.array_equal(b_d, b_s) and np.array_equal(dense.palette_map, sparse.palette_map)
+    dense.close()
+    sparse.close()
+
+
 @pytest.mark.parametrize("flags", [{"dither": True}, {"perceptual": True}, {}], ids=["dither", "perceptual", "rgb"])
 @pytest.mark.parametrize("knobs", [{}, {"SNES_H2Q_MAX": "0", "SNES_DITHER4_MAX": "0"}, {"SNES_H2Q_MAX": "100000", "SNES_DITHER4_MAX": "100000"},
                                    {"SNES_VSPLIT": "0", "SNES_SCAN4_MAX": "0", "SNES_DOWN_TILES": "0", "SNES_H0_MIN": "0"}, {"SNES_SCAN4_MAX": "100000"}],
