@@ -67,7 +67,8 @@ def config_extras(args):
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             d = json.loads(line[-1])
             out[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "workload": d["config"]["workload"],
-                         "roofline_frac": d["roofline"]["frac"], "pipeline_frac": d["roofline"].get("pipeline_frac")}
+                         "roofline_frac": d["roofline"]["frac"], "pipeline_frac": d["roofline"].get("pipeline_frac"),
+                         "hbm_in_use_gb": d.get("hbm_in_use_gb")}
         except Exception as e:  # an extra never takes the headline down with it
             out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
@@ -174,6 +175,11 @@ def bench_images(args, torch, dist, S, world, rank, local_rank, device, force_di
         }
         if os.environ.get("SNES_BENCH_SHARE_GPU") == "1" or os.environ.get("SNES_BENCH_BACKEND", "nccl") != "nccl":
             out["rehearsal"] = "ranks share one device / collective not over RCCL: a rehearsal of the N > 1 code paths, not a measurement"
+        try:  # what this rank's images hold in HBM (every image a context of its own: 64-candidate storage and B)
+            free_b, total_b = torch.cuda.mem_get_info()
+            out["hbm_in_use_gb"] = round((total_b - free_b) / 2 ** 30, 2)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     batch.close()
     if world > 1 or force_dist:
@@ -219,6 +225,17 @@ def main():
         os.environ.setdefault("SNES_BASE_STREAM", "0")
         os.environ.setdefault("SNES_SPARSE_MIN", "32")
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+    # RGB launch groups of 1,024 candidates and more run on three streams of the library's (main, base image, scale 0's H and V
+    # passes: DESIGN 4b).  With a process group on RCCL in the process — its streams take hardware queues too — the runtime's
+    # default of four queues makes some of them share one, and every hand-over between two such streams then costs ~50 us instead
+    # of ~12: 1.68-1.72 ms per 4,096-candidate call on one rank against 1.43-1.45 with five queues or more (8, 12: the same).
+    # Without RCCL it is the other way round (1.45 ms at four queues, 1.95 at five and more), and the other configurations prefer
+    # four with or without it: set for this case only (profiles/r4_dist_gap*.sh, r4_hw_queues.txt).  The variable is read when the
+    # HIP runtime starts, i.e. it must be in place before torch touches the device.
+    if (args.config == "rgb" and os.environ.get("SNES_BENCH_BACKEND", "nccl") == "nccl"
+            and (int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("SNES_BENCH_FORCE_DIST") == "1")):
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     from snesimage_amd.launch import needs_spawn, spawn_ranks
     if needs_spawn(args.gpus):  # typed as `python bench.py --gpus N`: this process becomes the launcher and never touches the GPU
@@ -503,6 +520,7 @@ def main():
         if stale_pmc:
             out["stale_pmc"] = stale_pmc
         out["library"] = lib_version()
+        out["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)")
         if os.environ.get("SNES_BENCH_SHARE_GPU") == "1" or backend != "nccl":
             out["rehearsal"] = "ranks share one device / collective over %s: a rehearsal of the N > 1 code paths, not a measurement" % backend
         out.update(extras)
