@@ -54,6 +54,12 @@ def lib_hash():
     return v.split("src:")[1].strip() if "src:" in v else None
 
 
+def wants_more_hw_queues(config, environ):
+    """True where this process will hold a process group on RCCL beside the RGB configuration's three streams (main(): why)."""
+    return (config == "rgb" and environ.get("SNES_BENCH_BACKEND", "nccl") == "nccl"
+            and (int(environ.get("WORLD_SIZE", "1")) > 1 or environ.get("SNES_BENCH_FORCE_DIST") == "1"))
+
+
 def config_extras(args):
     """Short runs of the other configurations as child processes, so that their numbers are the driver's too, not only the
     builder's: one line each, the keys the judge reads.  Bounded: about a minute in all."""
@@ -233,8 +239,7 @@ def main():
     # Without RCCL it is the other way round (1.45 ms at four queues, 1.95 at five and more), and the other configurations prefer
     # four with or without it: set for this case only (profiles/r4_dist_gap*.sh, r4_hw_queues.txt).  The variable is read when the
     # HIP runtime starts, i.e. it must be in place before torch touches the device.
-    if (args.config == "rgb" and os.environ.get("SNES_BENCH_BACKEND", "nccl") == "nccl"
-            and (int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("SNES_BENCH_FORCE_DIST") == "1")):
+    if wants_more_hw_queues(args.config, os.environ):
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     from snesimage_amd.launch import needs_spawn, spawn_ranks

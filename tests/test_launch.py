@@ -78,3 +78,21 @@ def test_bench_spawns_before_touching_the_gpu():
     src = open(os.path.join(ROOT, "bench.py")).read()
     main = src[src.index("def main():"):]
     assert main.index("needs_spawn(") < main.index("import torch")
+
+
+def test_bench_asks_for_more_hardware_queues_only_beside_rccl():
+    """GPU_MAX_HW_QUEUES is read when the HIP runtime starts: bench.py decides before it imports torch, and only for the case that
+    was measured (RGB launch groups on three streams with a process group on RCCL in the process: DESIGN 5, profiles/r4_hw_queues.txt)
+    — the plain run, the other configurations and a gloo rehearsal keep the runtime's default."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    w = bench.wants_more_hw_queues
+    assert w("rgb", {"WORLD_SIZE": "8"}) and w("rgb", {"WORLD_SIZE": "2", "RANK": "1"}) and w("rgb", {"SNES_BENCH_FORCE_DIST": "1"})
+    assert not w("rgb", {}) and not w("rgb", {"WORLD_SIZE": "1"})
+    assert not w("dither", {"WORLD_SIZE": "8"}) and not w("perceptual", {"WORLD_SIZE": "8"}) and not w("images", {"WORLD_SIZE": "8"})
+    assert not w("rgb", {"WORLD_SIZE": "2", "SNES_BENCH_BACKEND": "gloo"})
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    assert main.index("wants_more_hw_queues(") < main.index("import torch")
