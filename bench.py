@@ -55,9 +55,11 @@ def lib_hash():
 
 
 def wants_more_hw_queues(config, environ):
-    """True where this process will hold a process group on RCCL beside the RGB configuration's three streams (main(): why)."""
-    return (config == "rgb" and environ.get("SNES_BENCH_BACKEND", "nccl") == "nccl"
-            and (int(environ.get("WORLD_SIZE", "1")) > 1 or environ.get("SNES_BENCH_FORCE_DIST") == "1"))
+    """True for the configuration whose launch groups run on three streams of the library's (main(): why)."""
+    return config == "rgb"
+
+
+_SET_HW_QUEUES = False  # main() put GPU_MAX_HW_QUEUES in the environment itself: the other configurations' child runs must not inherit it
 
 
 def config_extras(args):
@@ -68,8 +70,9 @@ def config_extras(args):
     for name, extra in (("perceptual", ["--config", "perceptual", "--steps", "60"]), ("dither", ["--config", "dither", "--steps", "24"]),
                         ("images", ["--config", "images", "--steps", "30"])):
         try:
+            env = {k: v for k, v in os.environ.items() if not (_SET_HW_QUEUES and k == "GPU_MAX_HW_QUEUES")}
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline", "--warmup", "5", *extra],
-                               capture_output=True, text=True, timeout=240)
+                               capture_output=True, text=True, timeout=240, env=env)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             d = json.loads(line[-1])
             out[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "workload": d["config"]["workload"],
@@ -233,14 +236,18 @@ def main():
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
     # RGB launch groups of 1,024 candidates and more run on three streams of the library's (main, base image, scale 0's H and V
-    # passes: DESIGN 4b).  With a process group on RCCL in the process — its streams take hardware queues too — the runtime's
-    # default of four queues makes some of them share one, and every hand-over between two such streams then costs ~50 us instead
-    # of ~12: 1.68-1.72 ms per 4,096-candidate call on one rank against 1.43-1.45 with five queues or more (8, 12: the same).
-    # Without RCCL it is the other way round (1.45 ms at four queues, 1.95 at five and more), and the other configurations prefer
-    # four with or without it: set for this case only (profiles/r4_dist_gap*.sh, r4_hw_queues.txt).  The variable is read when the
-    # HIP runtime starts, i.e. it must be in place before torch touches the device.
-    if wants_more_hw_queues(args.config, os.environ):
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # passes: DESIGN 4b), and a process group on RCCL brings streams of its own.  The runtime deals streams to four hardware queues by
+    # default; two streams that share a queue pay ~50 us for every hand-over between them instead of ~12.  Until the last session of
+    # round 4 the second launch lane's stream, created with the context and never used by this configuration, decided who shared with
+    # whom: 1.41-1.45 ms per 4,096-candidate call alone at four queues, 1.91-1.95 at five and more, 1.67-1.72 at four with RCCL in the
+    # process, 1.43 at five and more with it.  Lanes' streams are now created by the first list dealt to them and every combination is
+    # within 1.42-1.46 ms — five queues and more 1-2 % ahead of four, with and without RCCL (profiles/r4_hw_queues*.txt): asked for
+    # here, for this configuration only (--dither and --perceptual-palettes split every list over two lanes and are indifferent or
+    # 1 % better at four).  The variable is read when the HIP runtime starts: it must be in place before torch touches the device.
+    global _SET_HW_QUEUES
+    if wants_more_hw_queues(args.config, os.environ) and "GPU_MAX_HW_QUEUES" not in os.environ:
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
+        _SET_HW_QUEUES = True
 
     from snesimage_amd.launch import needs_spawn, spawn_ranks
     if needs_spawn(args.gpus):  # typed as `python bench.py --gpus N`: this process becomes the launcher and never touches the GPU

@@ -236,16 +236,22 @@ int32_t alloc_lane(snesimage_ctx *c, uint32_t chunk, float *&d_work, float *&d_c
     }
     return SNES_OK;
 }
-// grow-only: `chunk` = candidates per lane the dense kernels are about to handle
-int32_t alloc_workspace(snesimage_ctx *c, uint32_t chunk) {
-    if (c->chunk_alloc >= chunk && c->extra.size() + 1 >= c->nlanes) return SNES_OK;
+// grow-only: `chunk` = candidates per lane the dense kernels are about to handle, `lanes` = launch lanes the list at hand is dealt to.
+// A lane's stream is created by the first list that needs it: a stream that exists and never runs still takes its turn when the
+// runtime deals streams to hardware queues, and with the second lane's idle stream in the process the three streams of an RGB launch
+// group shared queues or not depending on GPU_MAX_HW_QUEUES and on whether RCCL had brought streams of its own — 1.41 against 1.67-1.95 ms
+// per 4,096-candidate call (profiles/r4_hw_queues_lanes.txt).
+int32_t alloc_workspace(snesimage_ctx *c, uint32_t chunk, uint32_t lanes = 1) {
+    if (lanes > c->nlanes) lanes = c->nlanes;
+    if (lanes < c->extra.size() + 1) lanes = (uint32_t)c->extra.size() + 1;
+    if (c->chunk_alloc >= chunk && c->extra.size() + 1 >= lanes) return SNES_OK;
     if (chunk < c->chunk_alloc) chunk = c->chunk_alloc;
     HIPCHK(hipStreamSynchronize(c->stream));
     for (auto &L : c->extra) HIPCHK(hipStreamSynchronize(L.stream));
     c->chunk_alloc = 0; // the buffers are about to be released: a failed grow must not leave the old capacity behind
     CHECK(alloc_lane(c, chunk, c->d_work, c->d_cand_tab, c->d_cand_lab, c->d_part, c->d_maps, c->d_mapsT, c->d_mapsC4, c->d_mapsR4));
     if (!c->ev_ready) HIPCHK(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
-    while (c->extra.size() + 1 < c->nlanes) {
+    while (c->extra.size() + 1 < lanes) {
         snesimage_ctx::Lane L;
         HIPCHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
@@ -256,6 +262,8 @@ int32_t alloc_workspace(snesimage_ctx *c, uint32_t chunk) {
         HIPCHK(dmalloc(&c->d_bestmaps_all, c->npx * (size_t)c->nlanes));
         HIPCHK(dmalloc(&c->d_bestrecs_all, sizeof(BestRec) * c->nlanes));
         HIPCHK(dmalloc(&c->d_skip, sizeof(int)));
+    }
+    if (c->d_bestmaps_all) { // (every lane's slot exists from the start; a lane created later finds its own)
         c->d_bestmap = c->d_bestmaps_all; c->d_bestrec = c->d_bestrecs_all;
         for (size_t l = 0; l < c->extra.size(); l++) { c->extra[l].d_bestmap = c->d_bestmaps_all + (l + 1) * c->npx; c->extra[l].d_bestrec = c->d_bestrecs_all + (l + 1); }
     }
@@ -824,11 +832,11 @@ int32_t score_list(snesimage_ctx *c, const uint8_t *d_rgb5, uint32_t n, double *
     // (--dither with one-entry subpalettes stays on the dense path: B then has no other entry to stand in for the slot's, so
     // the slot's index appears in B's map as well and a map comparison cannot tell the candidate's pixels from B's)
     const bool sparse = c->sp.enabled && !d_maps_out && sp >= 0 && n >= c->sp.min_n && c->pack_mode == (c->dither ? 1 : 2) && !(c->dither && c->sub_size == 1);
-    CHECK(alloc_workspace(c, sparse ? 1 : chunk));
-    CHECK(ensure_tables(c));
-    CHECK(ensure_source(c));
     const uint32_t nchunks = (n + chunk - 1) / chunk;
     const uint32_t nl = nchunks < c->nlanes ? nchunks : c->nlanes;
+    CHECK(alloc_workspace(c, sparse ? 1 : chunk, nl));
+    CHECK(ensure_tables(c));
+    CHECK(ensure_source(c));
     if (sparse) {
         CHECK(sparse_alloc(c, chunk, nl));
         if (c->dither && (c->sp.base_sp != sp || c->sp.base_si != si)) c->sp.plist_valid = false;

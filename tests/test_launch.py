@@ -80,19 +80,20 @@ def test_bench_spawns_before_touching_the_gpu():
     assert main.index("needs_spawn(") < main.index("import torch")
 
 
-def test_bench_asks_for_more_hardware_queues_only_beside_rccl():
-    """GPU_MAX_HW_QUEUES is read when the HIP runtime starts: bench.py decides before it imports torch, and only for the case that
-    was measured (RGB launch groups on three streams with a process group on RCCL in the process: DESIGN 5, profiles/r4_hw_queues.txt)
-    — the plain run, the other configurations and a gloo rehearsal keep the runtime's default."""
+def test_bench_asks_for_more_hardware_queues_for_the_rgb_configuration_only():
+    """GPU_MAX_HW_QUEUES is read when the HIP runtime starts: bench.py decides before it imports torch, for the configuration whose
+    launch groups run on three streams (profiles/r4_hw_queues*.txt), never over a value the caller has set, and the child
+    runs of the other configurations do not inherit it."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     w = bench.wants_more_hw_queues
-    assert w("rgb", {"WORLD_SIZE": "8"}) and w("rgb", {"WORLD_SIZE": "2", "RANK": "1"}) and w("rgb", {"SNES_BENCH_FORCE_DIST": "1"})
-    assert not w("rgb", {}) and not w("rgb", {"WORLD_SIZE": "1"})
-    assert not w("dither", {"WORLD_SIZE": "8"}) and not w("perceptual", {"WORLD_SIZE": "8"}) and not w("images", {"WORLD_SIZE": "8"})
-    assert not w("rgb", {"WORLD_SIZE": "2", "SNES_BENCH_BACKEND": "gloo"})
+    assert w("rgb", {}) and w("rgb", {"WORLD_SIZE": "8"}) and w("rgb", {"SNES_BENCH_FORCE_DIST": "1"})
+    assert not w("dither", {"WORLD_SIZE": "8"}) and not w("perceptual", {}) and not w("images", {"WORLD_SIZE": "8"})
     src = open(os.path.join(ROOT, "bench.py")).read()
     main = src[src.index("def main():"):]
     assert main.index("wants_more_hw_queues(") < main.index("import torch")
+    assert '"GPU_MAX_HW_QUEUES" not in os.environ' in main
+    extras = src[src.index("def config_extras("):src.index("def cpu_baseline(")]
+    assert "_SET_HW_QUEUES and k == \"GPU_MAX_HW_QUEUES\"" in extras and "env=env" in extras
