@@ -242,6 +242,10 @@ int32_t alloc_lane(snesimage_ctx *c, uint32_t chunk, float *&d_work, float *&d_c
 // group shared queues or not depending on GPU_MAX_HW_QUEUES and on whether RCCL had brought streams of its own — 1.41 against 1.67-1.95 ms
 // per 4,096-candidate call (profiles/r4_hw_queues_lanes.txt).
 int32_t alloc_workspace(snesimage_ctx *c, uint32_t chunk, uint32_t lanes = 1) {
+    // (--dither and --perceptual-palettes split every list over the lanes: theirs exist from the first call on, as they always did —
+    // created later, behind the caller's stream, the same three active streams drew worse queues: 5.2 -> 6.4 ms and 2.26 -> 2.45 ms per
+    // 4,096-candidate call, profiles/r4_hw_queues_dither.txt)
+    if (c->dither || c->perceptual) lanes = c->nlanes;
     if (lanes > c->nlanes) lanes = c->nlanes;
     if (lanes < c->extra.size() + 1) lanes = (uint32_t)c->extra.size() + 1;
     if (c->chunk_alloc >= chunk && c->extra.size() + 1 >= lanes) return SNES_OK;
