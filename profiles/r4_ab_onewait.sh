@@ -1,5 +1,6 @@
 #!/bin/bash
-# profiles/r4_ab_onewait.sh: a short list's V passes behind one wait for B's sweeps (SNES_ONE_WAIT=1) or one wait each (0):
+# profiles/r4_ab_onewait.sh: a short list's V passes behind one wait for B's sweeps (SNES_ONE_WAIT=1) or one wait each (0) — the knob existed in the
+# build this script measured (commit 8c8b6f9's parent working tree) and was removed with the experiment (-0.4 %, not kept):
 # the 64-candidate call, the 32-candidate channel calls, the reference's loop call by call and in adaptive windows.  Interleaved, same box.
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/ab_onewait; mkdir -p $O
