@@ -237,7 +237,8 @@ def main():
 
     # RGB launch groups of 1,024 candidates and more run on three streams of the library's (main, base image, scale 0's H and V
     # passes: DESIGN 4b), and a process group on RCCL brings streams of its own.  The runtime deals streams to four hardware queues by
-    # default; two streams that share a queue pay ~50 us for every hand-over between them instead of ~12.  Until the last session of
+    # default: two active streams that share a queue run in order, and — with more queues — two whose queues share a pipe (i, i + 4)
+    # pay ~50 us for every hand-over instead of ~15 (profiles/micro/stream_handover_mi355x.txt).  Until the last session of
     # round 4 the second launch lane's stream, created with the context and never used by this configuration, decided who shared with
     # whom: 1.41-1.45 ms per 4,096-candidate call alone at four queues, 1.91-1.95 at five and more, 1.67-1.72 at four with RCCL in the
     # process, 1.43 at five and more with it.  Lanes' streams are now created by the first list dealt to them and every combination is
